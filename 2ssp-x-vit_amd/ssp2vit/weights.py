@@ -1,0 +1,198 @@
+"""Flat ViT weight dictionary: the one format the HIP engine is loaded from.
+
+Keys (all tensors fp32, CPU, contiguous; layer index ``i`` in ``0..depth-1``)::
+
+    img patch dim heads depth classes eps            python scalars
+    patch_w [dim,3,p,p]  patch_b [dim]               conv k=s=p   (a3 in SURVEY.md §8a)
+    cls [1,1,dim]  pos [1,N,dim]
+    ln1_g.i ln1_b.i [dim]
+    qkv_w.i [3*dim,dim]  qkv_b.i [3*dim]             rows ordered [q|k|v][head][d_h]
+    proj_w.i [dim,dim]   proj_b.i [dim]
+    ln2_g.i ln2_b.i [dim]
+    fc1_w.i [d_int_i,dim] fc1_b.i [d_int_i]
+    fc2_w.i [dim,d_int_i] fc2_b.i [dim]
+    lnf_g lnf_b [dim]    head_w [classes,dim]  head_b [classes]
+
+``nn.Linear`` row-major ``[out,in]`` is kept as is: it is already the K-contiguous "B^T" layout
+the MFMA GEMM wants.  Anatomy adapters (``from_module``) accept the same three layouts the
+reference duck-types over (/root/reference/src/vit_pruning.py:27-67) plus the renamed layout of
+transformers>=5.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+# name -> (img, patch, dim, heads, d_int, depth)
+VIT_CONFIGS = {
+    "vit_tiny_patch16_224": (224, 16, 192, 3, 768, 12),
+    "vit_small_patch16_224": (224, 16, 384, 6, 1536, 12),
+    "vit_base_patch16_224": (224, 16, 768, 12, 3072, 12),
+    "vit_large_patch16_224": (224, 16, 1024, 16, 4096, 24),
+    "vit_huge_patch14_224": (224, 14, 1280, 16, 5120, 32),
+    # the reference's own smoke-test config (experiments/vit_pruning/test_stage2_attention_only.py:44-53)
+    "vit_test_patch16_32": (32, 16, 64, 4, 128, 4),
+}
+
+
+def n_tokens(w: Dict) -> int:
+    return (int(w["img"]) // int(w["patch"])) ** 2 + 1
+
+
+def synthetic_weights(name: str = "vit_base_patch16_224", classes: int = 1000, seed: int = 0,
+                      std: float = 0.02, eps: float = 1e-6, spread: Optional[float] = None,
+                      bias_std: float = 0.0) -> Dict:
+    """Seeded random-init weights of a named architecture (no checkpoints exist offline).
+
+    trunc-normal(std) matrices, LN gamma=1 beta=0, zero (or N(0,bias_std)) biases.  ``spread`` scales
+    fc1 rows by a log-uniform factor in [1/spread, spread] so stage-1 scores are well separated
+    (SURVEY.md §8d).
+    """
+    img, patch, dim, heads, inter, depth = VIT_CONFIGS[name]
+    g = torch.Generator().manual_seed(seed)
+
+    def tn(*shape, s=std):
+        t = torch.empty(*shape)
+        torch.nn.init.trunc_normal_(t, std=s, a=-2 * s, b=2 * s, generator=g)
+        return t
+
+    def bias(n):
+        return torch.randn(n, generator=g) * bias_std if bias_std > 0 else torch.zeros(n)
+
+    n_tok = (img // patch) ** 2 + 1
+    w: Dict = dict(img=img, patch=patch, dim=dim, heads=heads, depth=depth, classes=classes, eps=eps)
+    w["patch_w"] = tn(dim, 3, patch, patch)
+    w["patch_b"] = bias(dim)
+    w["cls"] = tn(1, 1, dim)
+    w["pos"] = tn(1, n_tok, dim)
+    for i in range(depth):
+        w[f"ln1_g.{i}"] = torch.ones(dim); w[f"ln1_b.{i}"] = torch.zeros(dim)
+        w[f"qkv_w.{i}"] = tn(3 * dim, dim); w[f"qkv_b.{i}"] = bias(3 * dim)
+        w[f"proj_w.{i}"] = tn(dim, dim); w[f"proj_b.{i}"] = bias(dim)
+        w[f"ln2_g.{i}"] = torch.ones(dim); w[f"ln2_b.{i}"] = torch.zeros(dim)
+        fc1 = tn(inter, dim)
+        if spread is not None and spread > 1.0:
+            u = torch.rand(inter, generator=g) * 2 - 1
+            fc1 = fc1 * torch.exp(u * math.log(spread)).unsqueeze(1)
+        w[f"fc1_w.{i}"] = fc1; w[f"fc1_b.{i}"] = bias(inter)
+        w[f"fc2_w.{i}"] = tn(dim, inter); w[f"fc2_b.{i}"] = bias(dim)
+    w["lnf_g"] = torch.ones(dim); w["lnf_b"] = torch.zeros(dim)
+    w["head_w"] = tn(classes, dim); w["head_b"] = bias(classes)
+    return w
+
+
+def count_params(w: Dict) -> int:
+    return sum(int(v.numel()) for v in w.values() if isinstance(v, torch.Tensor))
+
+
+# ----------------------------------------------------------------------------- anatomy adapters
+def _f32(t) -> torch.Tensor:
+    return t.detach().to("cpu", torch.float32).contiguous()
+
+
+def detect_layout(model) -> str:
+    """'timm' | 'hf' (transformers<5: vit.encoder.layer) | 'hf5' (transformers>=5: vit.layers)."""
+    if hasattr(model, "blocks") and hasattr(model, "patch_embed"):
+        return "timm"
+    base = getattr(model, "vit", None) or getattr(model, "base_model", None) or model
+    enc = getattr(base, "encoder", base)
+    if hasattr(enc, "layer"):
+        return "hf"
+    if hasattr(base, "layers") or hasattr(enc, "layers"):
+        return "hf5"
+    raise AttributeError("Unsupported ViT model structure: expected encoder.layer or blocks")
+
+
+def score_site_for(layout: str) -> str:
+    """Where the reference's stage-1 hook lands (vit_pruning.py:130 vs :135)."""
+    return "pre_gelu" if layout == "timm" else "post_gelu"
+
+
+def from_module(model) -> Dict:
+    """Extract the flat dictionary from a live module (weights are copied, the module is untouched)."""
+    layout = detect_layout(model)
+    w: Dict = {}
+    if layout == "timm":
+        pe = model.patch_embed.proj
+        blocks = list(model.blocks)
+        w["patch_w"], w["patch_b"] = _f32(pe.weight), _f32(pe.bias)
+        w["cls"], w["pos"] = _f32(model.cls_token), _f32(model.pos_embed)
+        for i, b in enumerate(blocks):
+            w[f"ln1_g.{i}"], w[f"ln1_b.{i}"] = _f32(b.norm1.weight), _f32(b.norm1.bias)
+            attn = getattr(b, "attn", None)
+            if attn is not None and hasattr(attn, "qkv"):
+                w[f"qkv_w.{i}"], w[f"qkv_b.{i}"] = _f32(attn.qkv.weight), _f32(attn.qkv.bias)
+                w[f"proj_w.{i}"], w[f"proj_b.{i}"] = _f32(attn.proj.weight), _f32(attn.proj.bias)
+            else:  # attention already replaced by a bypass (a6): zero weights + skip flag
+                w[f"attn_absent.{i}"] = True
+            w[f"ln2_g.{i}"], w[f"ln2_b.{i}"] = _f32(b.norm2.weight), _f32(b.norm2.bias)
+            w[f"fc1_w.{i}"], w[f"fc1_b.{i}"] = _f32(b.mlp.fc1.weight), _f32(b.mlp.fc1.bias)
+            w[f"fc2_w.{i}"], w[f"fc2_b.{i}"] = _f32(b.mlp.fc2.weight), _f32(b.mlp.fc2.bias)
+        w["lnf_g"], w["lnf_b"] = _f32(model.norm.weight), _f32(model.norm.bias)
+        w["head_w"], w["head_b"] = _f32(model.head.weight), _f32(model.head.bias)
+        eps = float(model.norm.eps)
+        heads = int(blocks[0].attn.num_heads) if hasattr(blocks[0].attn, "num_heads") else None
+    elif layout == "hf":
+        vit = model.vit if hasattr(model, "vit") else model
+        emb = vit.embeddings
+        pe = emb.patch_embeddings.projection
+        layers = list(vit.encoder.layer)
+        w["patch_w"], w["patch_b"] = _f32(pe.weight), _f32(pe.bias)
+        w["cls"], w["pos"] = _f32(emb.cls_token), _f32(emb.position_embeddings)
+        for i, l in enumerate(layers):
+            w[f"ln1_g.{i}"], w[f"ln1_b.{i}"] = _f32(l.layernorm_before.weight), _f32(l.layernorm_before.bias)
+            att = getattr(l, "attention", None)
+            sa = getattr(att, "attention", None)
+            if sa is not None and hasattr(sa, "query"):
+                w[f"qkv_w.{i}"] = torch.cat([_f32(sa.query.weight), _f32(sa.key.weight), _f32(sa.value.weight)], 0)
+                w[f"qkv_b.{i}"] = torch.cat([_f32(sa.query.bias), _f32(sa.key.bias), _f32(sa.value.bias)], 0)
+                w[f"proj_w.{i}"], w[f"proj_b.{i}"] = _f32(att.output.dense.weight), _f32(att.output.dense.bias)
+            else:
+                w[f"attn_absent.{i}"] = True
+            w[f"ln2_g.{i}"], w[f"ln2_b.{i}"] = _f32(l.layernorm_after.weight), _f32(l.layernorm_after.bias)
+            w[f"fc1_w.{i}"], w[f"fc1_b.{i}"] = _f32(l.intermediate.dense.weight), _f32(l.intermediate.dense.bias)
+            w[f"fc2_w.{i}"], w[f"fc2_b.{i}"] = _f32(l.output.dense.weight), _f32(l.output.dense.bias)
+        w["lnf_g"], w["lnf_b"] = _f32(vit.layernorm.weight), _f32(vit.layernorm.bias)
+        w["head_w"], w["head_b"] = _f32(model.classifier.weight), _f32(model.classifier.bias)
+        eps = float(vit.layernorm.eps)
+        heads = int(getattr(model.config, "num_attention_heads"))
+    else:  # hf5: vit.layers[i].{layernorm_before, attention.{q,k,v,o}_proj, layernorm_after, mlp.fc1/fc2}
+        vit = model.vit if hasattr(model, "vit") else model
+        emb = vit.embeddings
+        pe = emb.patch_embeddings.projection
+        layers = list(getattr(vit, "layers", None) or vit.encoder.layers)
+        w["patch_w"], w["patch_b"] = _f32(pe.weight), _f32(pe.bias)
+        w["cls"], w["pos"] = _f32(emb.cls_token), _f32(emb.position_embeddings)
+        for i, l in enumerate(layers):
+            w[f"ln1_g.{i}"], w[f"ln1_b.{i}"] = _f32(l.layernorm_before.weight), _f32(l.layernorm_before.bias)
+            a = l.attention
+            if hasattr(a, "q_proj"):
+                w[f"qkv_w.{i}"] = torch.cat([_f32(a.q_proj.weight), _f32(a.k_proj.weight), _f32(a.v_proj.weight)], 0)
+                w[f"qkv_b.{i}"] = torch.cat([_f32(a.q_proj.bias), _f32(a.k_proj.bias), _f32(a.v_proj.bias)], 0)
+                w[f"proj_w.{i}"], w[f"proj_b.{i}"] = _f32(a.o_proj.weight), _f32(a.o_proj.bias)
+            else:
+                w[f"attn_absent.{i}"] = True
+            w[f"ln2_g.{i}"], w[f"ln2_b.{i}"] = _f32(l.layernorm_after.weight), _f32(l.layernorm_after.bias)
+            w[f"fc1_w.{i}"], w[f"fc1_b.{i}"] = _f32(l.mlp.fc1.weight), _f32(l.mlp.fc1.bias)
+            w[f"fc2_w.{i}"], w[f"fc2_b.{i}"] = _f32(l.mlp.fc2.weight), _f32(l.mlp.fc2.bias)
+        w["lnf_g"], w["lnf_b"] = _f32(vit.layernorm.weight), _f32(vit.layernorm.bias)
+        w["head_w"], w["head_b"] = _f32(model.classifier.weight), _f32(model.classifier.bias)
+        eps = float(vit.layernorm.eps)
+        heads = int(getattr(model.config, "num_attention_heads"))
+
+    dim = int(w["patch_w"].shape[0])
+    patch = int(w["patch_w"].shape[-1])
+    n_tok = int(w["pos"].shape[1])
+    side = int(round(math.sqrt(n_tok - 1)))
+    depth = sum(1 for k in w if k.startswith("ln1_g."))
+    if heads is None:
+        heads = max(1, dim // 64)
+    for i in range(depth):  # bypassed attention: supply zero weights, the engine skips the block anyway
+        if w.get(f"attn_absent.{i}"):
+            w[f"qkv_w.{i}"] = torch.zeros(3 * dim, dim); w[f"qkv_b.{i}"] = torch.zeros(3 * dim)
+            w[f"proj_w.{i}"] = torch.zeros(dim, dim); w[f"proj_b.{i}"] = torch.zeros(dim)
+    w.update(img=side * patch, patch=patch, dim=dim, heads=heads, depth=depth,
+             classes=int(w["head_w"].shape[0]), eps=eps, layout=layout)
+    return w

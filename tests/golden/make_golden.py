@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Fixture generator — runs ONLY in the build container (needs /root/reference, which never travels).
+
+Imports the real reference (`/root/reference/src/vit_pruning.py`,
+`/root/reference/adaptation-for-Pures-framework/mask_conjunction.py`), drives it with the build-owned
+duck-typed modules of `oracle/vit_modules.py` on seeded inputs and writes DATA ONLY (inputs + the
+reference's outputs) to `tests/golden/*.npz|*.json`.  No reference source text is stored.
+
+    python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "2ssp-x-vit_amd"))
+
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(REF, "adaptation-for-Pures-framework"))  # mask_conjunction + its src/
+import mask_conjunction as ref_mc  # noqa: E402
+from src import vit_pruning as ref_vp  # noqa: E402
+
+from oracle.vit_modules import build_from_flat, TimmLayoutViT  # noqa: E402
+from ssp2vit.weights import synthetic_weights, VIT_CONFIGS  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def make_batches(n_batches, bs, img, seed, model=None):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n_batches):
+        px = torch.randn(bs, 3, img, img, generator=g)
+        out.append({"pixel_values": px})
+    if model is not None:  # teacher labels: the dense model's own argmax under the reference's autocast
+        for b in out:
+            with torch.no_grad(), torch.autocast("cpu", enabled=True):
+                o = model(pixel_values=b["pixel_values"]) if hasattr(model, "vit") else model(b["pixel_values"])
+            logits = o.logits if hasattr(o, "logits") else o
+            b["labels"] = logits.argmax(-1)
+    return out
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    """bf16 tensors are stored as their raw uint16 bit patterns; fp32 as is."""
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().astype(np.int16).view(np.uint16)
+    return t.numpy()
+
+
+def tiny_case(layout: str, std: float):
+    """Reference smoke-test config (test_stage2_attention_only.py:44-53): img 32, patch 16, d 64, 4 heads,
+    d_int 128, 4 layers, 10 labels; 2 batches x 8 images N(0,1)."""
+    w = synthetic_weights("vit_test_patch16_32", classes=10, seed=0, std=std, bias_std=0.02,
+                          eps=1e-6 if layout == "timm" else 1e-12)
+    model = build_from_flat(w, layout)
+    batches = make_batches(2, 8, 32, seed=1, model=model)
+    # perturb a few teacher labels so the baseline is < 1 and clamping max(0, .) is exercised
+    batches[1]["labels"] = batches[1]["labels"].clone()
+    batches[1]["labels"][:2] = (batches[1]["labels"][:2] + 1) % 10
+
+    rec = {}
+    for k, v in w.items():
+        rec["w." + k] = v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    for i, b in enumerate(batches):
+        rec[f"px.{i}"] = b["pixel_values"].numpy()
+        rec[f"labels.{i}"] = b["labels"].numpy()
+
+    imps = ref_vp._compute_ffn_activation_importance(model, batches, device="cpu", batch_limit=None)
+    assert all(t.dtype == torch.bfloat16 for t in imps)
+    for i, t in enumerate(imps):
+        rec[f"s1_imp_bf16bits.{i}"] = bits(t)
+    imps1 = ref_vp._compute_ffn_activation_importance(model, batches, device="cpu", batch_limit=1)
+    for i, t in enumerate(imps1):
+        rec[f"s1_imp_limit1_bf16bits.{i}"] = bits(t)
+
+    rec["top1"] = np.float64(ref_vp.evaluate_top1(model, batches, device="cpu"))
+    rec["top1_limit1"] = np.float64(ref_vp.evaluate_top1(model, batches, device="cpu", max_batches=1))
+
+    iface = ref_mc.Auto2SSPInterface(model, batches, device="cpu", importance_mode="copy", batch_limit=5)
+    rec["att_imp"] = quiet(iface._compute_att_depth_importance).numpy()
+    mlp_imp = quiet(iface._compute_mlp_importance)
+    for i, t in enumerate(mlp_imp):
+        assert torch.equal(t, imps[i])
+
+    # mask step on the CLI's fp32 cast of the scores (auto_2ssp.py:809), two prune counts
+    import copy
+    for tag, n_prune, min_rem in (("t40", 40, 16), ("t100_clamped", 100, 64)):
+        res = quiet(ref_vp.prune_vit_mlp_width, copy.deepcopy(model), n_to_prune_per_block=[n_prune] * 4,
+                    min_remaining=min_rem, collect_masks=True,
+                    precomputed_importance=[x.to(torch.float32) for x in imps])
+        rec[f"mask.{tag}"] = np.asarray(res["ffn_prune_masks"], dtype=np.int16)
+        rec[f"pruned_idx.{tag}"] = np.asarray(res["ffn_pruned_indices"], dtype=np.int64)
+        pm = res["model"]
+        rec[f"top1_after.{tag}"] = np.float64(ref_vp.evaluate_top1(pm, batches, device="cpu"))
+
+    # stage-2 through the function API: copy mode (search) and selected_indices (apply only)
+    res = quiet(ref_vp.prune_vit_attention_blocks, copy.deepcopy(model), sparsity=0.5, dataloader=batches,
+                device="cpu", batch_limit=5, importance_mode="copy", show_progress=False, num_to_prune=2)
+    rec["s2_copy.pruned"] = np.asarray(res["pruned_indices"], dtype=np.int64)
+    rec["s2_copy.orig"] = np.float64(res["original_metrics"])
+    rec["s2_copy.final"] = np.float64(res["final_metrics"])
+    res = quiet(ref_vp.prune_vit_attention_blocks, copy.deepcopy(model), sparsity=0.5, dataloader=None,
+                device="cpu", importance_mode="heuristic", show_progress=False, num_to_prune=2)
+    rec["s2_heur.pruned"] = np.asarray(res["pruned_indices"], dtype=np.int64)
+    sel = [int(i) for i in torch.argsort(torch.from_numpy(rec["att_imp"]))[:2]]
+    res = quiet(ref_vp.prune_vit_attention_blocks, copy.deepcopy(model), sparsity=0.5, dataloader=batches,
+                device="cpu", batch_limit=5, num_to_prune=2, selected_indices=sel, show_progress=False)
+    rec["s2_sel.pruned"] = np.asarray(res["pruned_indices"], dtype=np.int64)
+    rec["s2_sel.final"] = np.float64(res["final_metrics"])
+
+    np.savez_compressed(os.path.join(HERE, f"tiny_{layout}.npz"), **rec)
+    print(f"[golden] tiny_{layout}: top1={rec['top1']:.4f} att_imp={rec['att_imp'].tolist()} "
+          f"s2_copy={rec['s2_copy.pruned'].tolist()} distinct_labels={len(set(torch.cat([b['labels'] for b in batches]).tolist()))}")
+
+
+def vit_tiny_case():
+    """BASELINE.json configs[0]: ViT-Tiny/16, 32 calibration images, stage-1 scoring only, CPU.
+    Weights/pixels are regenerated from seeds (22 MB of fp32 is too large to commit)."""
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=0, std=0.02, eps=1e-6)
+    model = build_from_flat(w, "timm")
+    batches = make_batches(2, 16, 224, seed=1)
+    imps = ref_vp._compute_ffn_activation_importance(model, batches, device="cpu")
+    rec = {f"s1_imp_bf16bits.{i}": bits(t) for i, t in enumerate(imps)}
+    rec["weights_checksum"] = np.float64(sum(float(v.double().sum()) for v in w.values() if isinstance(v, torch.Tensor)))
+    rec["pixels_checksum"] = np.float64(sum(float(b["pixel_values"].double().sum()) for b in batches))
+    np.savez_compressed(os.path.join(HERE, "vit_tiny16_stage1.npz"), **rec)
+    print("[golden] vit_tiny16_stage1 written; distinct values in block 0:",
+          len(set(imps[0].float().tolist())))
+
+
+def planner_cases():
+    """plan_2ssp_allocation known answers on architecture-shaped modules (meta device: only numel is read)."""
+    out = []
+    cases = []
+    for name in ("vit_tiny_patch16_224", "vit_base_patch16_224", "vit_large_patch16_224", "vit_huge_patch14_224"):
+        for s in (0.25, 0.375, 0.5):
+            cases.append((name, 1000, s, 256 if "tiny" in name else 512, None))
+    for s, fb in ((0.1, None), (0.2, None), (0.3, None), (0.4, None), (0.3, 2), (0.05, None), (0.9, None), (0.3, 0)):
+        cases.append(("vit_base_patch16_224", 10, s, 512, fb))
+    cases.append(("vit_test_patch16_32", 10, 0.3, 16, None))
+    cases.append(("vit_test_patch16_32", 10, 0.02, 16, None))
+    for name, classes, s, min_rem, fb in cases:
+        img, patch, dim, heads, inter, depth = VIT_CONFIGS[name]
+        with torch.device("meta"):
+            m = TimmLayoutViT(img=img, patch=patch, dim=dim, heads=heads, inter=inter, depth=depth, classes=classes)
+        plan = quiet(ref_vp.plan_2ssp_allocation, m, s, min_remaining=min_rem, forced_blocks=fb)
+        out.append(dict(model=name, classes=classes, target=s, min_remaining=min_rem, forced_blocks=fb,
+                        total_params=int(ref_vp.count_total_params(m)),
+                        plan=dict(target_sparsity=plan.target_sparsity, num_blocks_total=plan.num_blocks_total,
+                                  blocks_to_prune=plan.blocks_to_prune,
+                                  per_block_neurons_to_prune=plan.per_block_neurons_to_prune,
+                                  stage2_fraction=plan.stage2_fraction,
+                                  estimated_total_removed_params=plan.estimated_total_removed_params,
+                                  est_error_params=plan.est_error_params)))
+        print(f"[golden] plan {name} C={classes} s={s} fb={fb}: K={plan.blocks_to_prune} "
+              f"t={plan.per_block_neurons_to_prune} err={plan.est_error_params}")
+    with open(os.path.join(HERE, "planner.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+def heuristic_and_exports():
+    out = {}
+    for B in (4, 12, 24, 32):
+        with torch.device("meta"):
+            m = TimmLayoutViT(img=32, patch=16, dim=64, heads=4, inter=128, depth=B, classes=10)
+        iface = ref_mc.Auto2SSPInterface(m, None, device="cpu", importance_mode="heuristic")
+        out[str(B)] = iface._compute_att_depth_importance().tolist()
+    with open(os.path.join(HERE, "heuristic_depth.json"), "w") as f:
+        json.dump(out, f)
+
+    # framework export schema (auto_2ssp.py:71-185) on a 2-block toy — written by the reference's own exporter
+    sys.path.insert(0, os.path.join(REF, "adaptation-for-Pures-framework"))
+    try:
+        import importlib
+        a2 = importlib.import_module("auto_2ssp")
+    except Exception as e:  # transformers/timm/datasets imports at module top may fail: ordinary error, skip
+        print("[golden] auto_2ssp import failed (ordinary error, exports fixture skipped):", repr(e)[:200])
+        return
+    import tempfile
+    from types import SimpleNamespace
+    with torch.device("cpu"):
+        m = build_from_flat(synthetic_weights("vit_test_patch16_32", classes=10, seed=3, std=0.2), "hf")
+    m.vit.encoder.layer = m.vit.encoder.layer[:2]
+    m.config = SimpleNamespace(hidden_size=4, num_attention_heads=2)
+    mlp_imp = [torch.tensor([0.5, 1.5, 0.25]), torch.tensor([2.0, 0.0, 1.0])]
+    att_imp = torch.tensor([0.125, 0.0])
+    masks = [[0, 0, 1], [0, 1, 0]]
+    with tempfile.TemporaryDirectory() as d:
+        prefix = os.path.join(d, "fw")
+        quiet(a2.build_framework_exports, prefix, m, mlp_imp, att_imp, masks, [1])
+        exp = {"inputs": {"mlp_imp": [t.tolist() for t in mlp_imp], "att_imp": att_imp.tolist(),
+                          "ffn_masks": masks, "pruned_blocks": [1], "hidden": 4, "heads": 2},
+               "scores": json.load(open(prefix + "_scores.json")),
+               "masks": json.load(open(prefix + "_masks.json"))}
+    with open(os.path.join(HERE, "framework_export.json"), "w") as f:
+        json.dump(exp, f, indent=1)
+    print("[golden] framework_export.json written")
+
+
+if __name__ == "__main__":
+    tiny_case("timm", std=0.25)
+    tiny_case("hf", std=0.25)
+    vit_tiny_case()
+    planner_cases()
+    heuristic_and_exports()

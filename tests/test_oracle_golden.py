@@ -1,0 +1,117 @@
+"""Pin the CPU oracle (oracle/ref_cpu.py) to outputs of the REAL reference.
+
+The .npz fixtures were produced by tests/golden/make_golden.py, which imports /root/reference in the build
+container and stores data only.  Every comparison here is bit-exact (same torch CPU ops, same rounding chain).
+These tests are CPU-only; bf16 CPU GEMM results can depend on the host ISA, so they are the pin for THIS
+container's torch build, which is also where the goldens were captured.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, bf16_from_bits, load_tiny_golden
+from oracle import ref_cpu
+from oracle.vit_modules import build_from_flat
+
+
+@pytest.mark.parametrize("layout", ["timm", "hf"])
+def test_stage1_scores_bit_exact(layout):
+    w, batches, z = load_tiny_golden(layout)
+    model = build_from_flat(w, layout)
+    imps = ref_cpu.ffn_activation_importance(model, batches)
+    assert len(imps) == 4
+    for i, t in enumerate(imps):
+        assert t.dtype == torch.bfloat16 and t.shape == (128,)
+        assert torch.equal(t.view(torch.int16), bf16_from_bits(z[f"s1_imp_bf16bits.{i}"]).view(torch.int16))
+    imps1 = ref_cpu.ffn_activation_importance(model, batches, batch_limit=1)
+    for i, t in enumerate(imps1):
+        assert torch.equal(t.view(torch.int16), bf16_from_bits(z[f"s1_imp_limit1_bf16bits.{i}"]).view(torch.int16))
+
+
+def test_pre_vs_post_gelu_sites_differ():
+    """timm hooks fc1 (pre-GELU), HF hooks `intermediate` (post-GELU): same weights, different scores."""
+    wt, bt, zt = load_tiny_golden("timm")
+    wh, bh, zh = load_tiny_golden("hf")
+    assert not np.array_equal(zt["s1_imp_bf16bits.0"], zh["s1_imp_bf16bits.0"])
+
+
+@pytest.mark.parametrize("layout", ["timm", "hf"])
+def test_top1_and_depth_importance_bit_exact(layout):
+    w, batches, z = load_tiny_golden(layout)
+    model = build_from_flat(w, layout)
+    assert ref_cpu.evaluate_top1(model, batches) == float(z["top1"])
+    assert ref_cpu.evaluate_top1(model, batches, max_batches=1) == float(z["top1_limit1"])
+    att = ref_cpu.att_depth_importance(model, batches, batch_limit=5)
+    assert att.dtype == torch.float32
+    assert np.array_equal(att.numpy(), z["att_imp"])
+    assert (z["att_imp"] >= 0).all()
+    # both selection rules of the reference
+    assert sorted(ref_cpu.select_blocks_python_sort(att.tolist(), 2)) == z["s2_copy.pruned"].tolist()  # :517 sorts
+    assert ref_cpu.select_blocks_torch_argsort(att, 2) == z["s2_sel.pruned"].tolist()
+    # applying the selection and re-evaluating reproduces the reference's final metric
+    m2 = copy.deepcopy(model)
+    for i in z["s2_copy.pruned"].tolist():
+        ref_cpu.bypass_attention_(m2, i)
+    assert ref_cpu.evaluate_top1(m2, batches, 5) == float(z["s2_copy.final"])
+    assert float(z["s2_copy.orig"]) == float(z["top1"])
+
+
+@pytest.mark.parametrize("layout", ["timm", "hf"])
+def test_mask_step_bit_exact(layout):
+    w, batches, z = load_tiny_golden(layout)
+    imps = [bf16_from_bits(z[f"s1_imp_bf16bits.{i}"]).to(torch.float32) for i in range(4)]
+    masks, idx = ref_cpu.width_prune_selection(imps, [40] * 4, min_remaining=16)
+    assert np.array_equal(np.asarray(masks, dtype=np.int16), z["mask.t40"])
+    assert np.array_equal(np.asarray(idx), z["pruned_idx.t40"])
+    assert all(sum(m) == 40 for m in masks)
+    # min_remaining clamp: 128 - 100 < 64  ->  prune 64
+    masks, idx = ref_cpu.width_prune_selection(imps, [100] * 4, min_remaining=64)
+    assert np.array_equal(np.asarray(masks, dtype=np.int16), z["mask.t100_clamped"])
+    assert all(sum(m) == 64 for m in masks)
+    # n_prune <= 0 blocks contribute no entry (reference `continue`)
+    masks, _ = ref_cpu.width_prune_selection(imps, [0, 5, 0, 5], min_remaining=16)
+    assert len(masks) == 2
+
+
+def test_heuristic_depth_scores():
+    import json, os
+    gold = json.load(open(os.path.join(GOLDEN, "heuristic_depth.json")))
+    for b, vals in gold.items():
+        assert ref_cpu.heuristic_depth_scores(int(b)).tolist() == vals
+
+
+def test_vit_tiny_config0_stage1_bit_exact():
+    """BASELINE.json configs[0]: ViT-Tiny/16, 32 calibration images, stage-1 FFN scoring on CPU."""
+    import os
+    from ssp2vit.weights import synthetic_weights
+    z = dict(np.load(os.path.join(GOLDEN, "vit_tiny16_stage1.npz")))
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=0, std=0.02, eps=1e-6)
+    chk = sum(float(v.double().sum()) for v in w.values() if isinstance(v, torch.Tensor))
+    assert chk == float(z["weights_checksum"]), "seeded weight generation drifted"
+    g = torch.Generator().manual_seed(1)
+    batches = [{"pixel_values": torch.randn(16, 3, 224, 224, generator=g)} for _ in range(2)]
+    model = build_from_flat(w, "timm")
+    imps = ref_cpu.ffn_activation_importance(model, batches)
+    assert len(imps) == 12
+    for i, t in enumerate(imps):
+        assert torch.equal(t.view(torch.int16), bf16_from_bits(z[f"s1_imp_bf16bits.{i}"]).view(torch.int16))
+
+
+def test_fp32_chain_close_to_autocast_chain():
+    """The engine's default fp32 score chain only removes the bf16 rounding of the reference chain."""
+    w, batches, z = load_tiny_golden("timm")
+    model = build_from_flat(w, "timm")
+    a = ref_cpu.ffn_activation_importance(model, batches, chain="autocast")
+    b = ref_cpu.ffn_activation_importance(model, batches, chain="fp32")
+    for x, y in zip(a, b):
+        assert y.dtype == torch.float32
+        assert torch.allclose(x.float(), y, rtol=2e-2, atol=1e-3)
+
+
+def test_act_l2_f64_statement():
+    rng = np.random.default_rng(0)
+    act = rng.standard_normal((3, 5, 7)).astype(np.float32)
+    ref = torch.linalg.vector_norm(torch.from_numpy(act).double(), ord=2, dim=1).sum(0).numpy()
+    assert np.allclose(ref_cpu.act_l2_accum_f64(act), ref, rtol=1e-14)
