@@ -1,0 +1,155 @@
+// Multi-head self-attention for ViT sequence lengths (197 / 257 tokens): one workgroup per (image, head),
+// the whole K and V of that head live in LDS, the whole score row of a query lives in registers, so the
+// softmax is exact single-pass (no online rescaling) and nothing N x N ever touches HBM.
+//
+// MFMA orientation (v_mfma_f32_32x32x16_bf16, 64-wide waves):
+//   S^T tile [32 keys x 32 queries] = K_tile (A operand, ds_read_b128 from LDS)  x  Q^T (B operand, registers)
+//     -> accumulator: lane <-> query, registers <-> keys: row max / row sum are in-lane reductions plus one
+//        exchange between the two 32-lane halves.
+//   O^T tile [32 d_h x 32 queries] = V^T (A operand) x P^T (B operand).  P^T is the S^T accumulator itself,
+//     converted to bf16 in registers (an accumulator tile is a valid B operand when the next product sums over
+//     its ROW index); V^T fragments come straight from the row-major V image with ds_read_b64_tr_b16
+//     (hardware transpose read), so V is staged exactly like K — no transposed LDS writes.
+//
+// qkv layout: [n*tokens, 3*dim] bf16, columns [q | k | v][head][d_h] (timm's fused qkv == concat of HF q,k,v).
+#pragma once
+#include "common.hip.h"
+
+template <int DH, int NT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
+                                                      int ldo, int tokens, int dim, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DT = (DH + 31) / 32;     // 32-row tiles of the O^T output (d_h padded up)
+  constexpr int KS = DH / 16;            // k-steps of the QK^T product
+  constexpr int KSB = DH * 2 + 16;       // K row stride (bytes): conflict-free ds_read_b128
+  constexpr int VSB = 192;               // V row stride (bytes): 48 dwords -> 4 rows x 16 dwords tile 64 banks
+  constexpr int NKEY = NT * 32;
+  constexpr int CH = DH / 8;
+  static_assert(DT * 32 * 2 <= VSB, "V row does not fit its LDS stride");
+
+  char* Ks = smem;
+  char* Vs = smem + NKEY * KSB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.x, img = blockIdx.y;
+  const bf16* base = qkv + (size_t)img * tokens * ld + head * DH;
+
+  // ---- stage K, V (zero rows past `tokens`, zero V columns past d_h: 0 * garbage would be NaN-unsafe)
+  for (int idx = tid; idx < NKEY * CH; idx += 256) {
+    const int key = idx / CH, c = idx - key * CH;
+    bf16x8 kv, vv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
+    if (key < tokens) {
+      const bf16* rowp = base + (size_t)key * ld + c * 8;
+      kv = *(const bf16x8*)(rowp + dim);
+      vv = *(const bf16x8*)(rowp + 2 * dim);
+    }
+    *(bf16x8*)(Ks + key * KSB + c * 16) = kv;
+    *(bf16x8*)(Vs + key * VSB + c * 16) = vv;
+  }
+  if (DT * 32 > DH) {
+    constexpr int PC = (DT * 32 - DH) / 8;
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+    for (int idx = tid; idx < NKEY * PC; idx += 256) {
+      const int key = idx / PC, c = idx - key * PC;
+      *(bf16x8*)(Vs + key * VSB + (CH + c) * 16) = z;
+    }
+  }
+  __syncthreads();
+
+  // per-lane constants of the transposed V read: 16-lane group -> 16 d_h columns, lane 4q+p -> row q, cols 4p..
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
+  const int v_lane_off = (4 * lh + tr_q) * VSB + (16 * tr_g + 4 * tr_p) * 2;
+
+  for (int qt = wave; qt < NT; qt += 4) {            // wave-uniform trip count: EXEC stays full
+    const int q = qt * 32 + l31;
+    const int qc = q < tokens ? q : tokens - 1;
+    const bf16* qp = base + (size_t)qc * ld + 8 * lh;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+
+    f32x16 sacc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[kt][i] = 0.f;
+      const char* kp = Ks + (kt * 32 + l31) * KSB + 16 * lh;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 kf = *(const bf16x8*)(kp + 32 * s);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
+      }
+    }
+    // ---- softmax over keys (registers + the other lane half)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        const float v = key < tokens ? sacc[kt][i] * scale : -INFINITY;
+        sacc[kt][i] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e = __expf(sacc[kt][i] - mx);
+        sacc[kt][i] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    // ---- O^T = V^T P^T
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s2 + j];
+        const char* vp = Vs + (kt * 32 + 16 * s2) * VSB + v_lane_off;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(vp + dt * 64));
+          const bf16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(vp + dt * 64 + 8 * VSB));
+          bf16x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { vf[j] = v1[j]; vf[4 + j] = v2[j]; }
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+      }
+    }
+    // ---- store: lane <-> query row, 4 consecutive d_h per 8-byte store
+    if (q < tokens) {
+      bf16* op = out + ((size_t)img * tokens + q) * ldo + head * DH;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d0 = dt * 32 + 8 * g4 + 4 * lh;
+          if (d0 < DH) {
+            bf16x4 o4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o4[j] = (bf16)(oacc[dt][4 * g4 + j] * inv);
+            *(bf16x4*)(op + d0) = o4;
+          }
+        }
+    }
+  }
+}

@@ -1,0 +1,475 @@
+// libssp2vit: C ABI (include/ssp2vit.h) + host-side orchestration of the gfx950 kernels.
+// Host code is plain C++: shape checks, weight conversion/padding, workspace carving, kernel launches on the
+// handle's HIP stream.  No allocation, synchronisation or host<->device copy happens inside the forward
+// calls (ssp2_embed / ssp2_layers / ssp2_head), so a caller may capture them into a hipGraph.
+#include "../../include/ssp2vit.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "attn.hip.h"
+#include "gemm.hip.h"
+#include "misc.hip.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(SSP2_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+  } while (0)
+
+static inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// fp32 -> bf16 bits, round-to-nearest-even, NaN kept quiet (matches torch .to(bfloat16))
+static inline uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf2f(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// ------------------------------------------------------------------------------------------------ engine
+struct Mat {            // bf16 weight matrix [rows_pad, ld] zero padded
+  bf16* w = nullptr;
+  float* b = nullptr;   // [rows_pad] fp32 holding bf16-rounded values
+  int rows = 0, rows_pad = 0, cols = 0, ld = 0;
+  bool w_set = false, b_set = false;
+};
+struct Layer {
+  float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+  bool ln_set[4] = {false, false, false, false};
+  Mat qkv, proj, fc1, fc2;
+  int d_int = 0, ld_int = 0;
+};
+
+struct ssp2_engine {
+  ssp2_vit_desc d{};
+  std::vector<int32_t> d_int;
+  int tokens = 0, patches = 0, side = 0, dh = 0;
+  int kpe = 0, kpe_pad = 0, ld_int_max = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  size_t ws_bytes = 0, weight_bytes = 0;
+
+  Mat patch, head;
+  float *cls = nullptr, *pos = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
+  bool misc_set[4] = {false, false, false, false};
+  std::vector<Layer> layers;
+
+  // workspace (sized for max_images)
+  bf16 *a_pe = nullptr, *hbuf = nullptr, *qkvbuf = nullptr, *obuf = nullptr, *actbuf = nullptr, *cls_h = nullptr;
+  bf16* prebuf = nullptr;   // pre-GELU copy, only for models with < 128 tokens (unfused scoring)
+  float *slab = nullptr, *norms = nullptr, *logits = nullptr;
+
+  // profiling
+  int prof_class = -1;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+};
+
+template <typename T>
+static int dalloc(ssp2_engine* e, T** p, size_t count, bool workspace) {
+  void* q = nullptr;
+  size_t bytes = count * sizeof(T);
+  if (bytes == 0) bytes = 16;
+  if (hipMalloc(&q, bytes) != hipSuccess) return fail(SSP2_ENOMEM, "hipMalloc(%zu) failed", bytes);
+  if (hipMemset(q, 0, bytes) != hipSuccess) return fail(SSP2_EHIP, "hipMemset failed");
+  e->allocs.push_back(q);
+  (workspace ? e->ws_bytes : e->weight_bytes) += bytes;
+  *p = (T*)q;
+  return 0;
+}
+
+static int mat_alloc(ssp2_engine* e, Mat& m, int rows, int cols) {
+  m.rows = rows; m.cols = cols;
+  m.rows_pad = ceil_to(rows, GEMM_BN);
+  m.ld = ceil_to(cols, GEMM_BK);
+  int rc;
+  if ((rc = dalloc(e, &m.w, (size_t)m.rows_pad * m.ld, false))) return rc;
+  if ((rc = dalloc(e, &m.b, (size_t)m.rows_pad, false))) return rc;
+  return 0;
+}
+
+struct ProfScope {
+  ssp2_engine* e; bool on; hipEvent_t a{}, b{};
+  ProfScope(ssp2_engine* e_, int klass) : e(e_), on(e_->prof_class == klass) {
+    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, e->stream); }
+  }
+  ~ProfScope() {
+    if (on) { hipEventRecord(b, e->stream); e->prof_events.emplace_back(a, b); }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ launches
+template <int EPI>
+static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
+  if (g.K % GEMM_BK) return fail(SSP2_EINVAL, "GEMM K=%d not a multiple of %d", g.K, GEMM_BK);
+  g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
+  if (g.tiles_m <= 0 || g.tiles_n <= 0) return fail(SSP2_EINVAL, "empty GEMM");
+  ProfScope ps(e, klass);
+  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, e->stream, g);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const float* g, const float* b, bf16* y,
+                     int out_ld, int rows, int D) {
+  ProfScope ps(e, SSP2_K_LN);
+  dim3 grid((rows + 3) / 4), blk(256);
+  if (D <= 64 * 4)
+    hipLaunchKernelGGL(layernorm_bf16_kernel<4>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
+  else if (D <= 64 * 12)
+    hipLaunchKernelGGL(layernorm_bf16_kernel<12>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
+  else if (D <= 64 * 32)
+    hipLaunchKernelGGL(layernorm_bf16_kernel<32>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
+  else
+    return fail(SSP2_EINVAL, "LayerNorm width %d > 2048 unsupported", D);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <int DH, int NT>
+static int launch_attn_t(ssp2_engine* e, int n) {
+  constexpr int smem = NT * 32 * (DH * 2 + 16) + NT * 32 * 192;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  ProfScope ps(e, SSP2_K_ATTN);
+  hipLaunchKernelGGL((attn_fwd_kernel<DH, NT>), dim3(e->d.heads, n), dim3(256), smem, e->stream, e->qkvbuf,
+                     3 * e->d.dim, e->obuf, e->d.dim, e->tokens, e->d.dim, 1.0f / sqrtf((float)DH));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int launch_attn(ssp2_engine* e, int n) {
+  const int nt = (e->tokens + 31) / 32;
+#define ATTN_CASE(DH_, NT_) if (e->dh == DH_ && nt == NT_) return launch_attn_t<DH_, NT_>(e, n)
+  ATTN_CASE(64, 7);   // 224/16: 197 tokens (Ti/S/B/L)
+  ATTN_CASE(80, 9);   // 224/14: 257 tokens (H/14)
+  ATTN_CASE(16, 1);   // reference smoke config: 32/16, 5 tokens
+  ATTN_CASE(64, 1);
+  ATTN_CASE(64, 2);   // 112/16: 50 tokens (test sizes)
+  ATTN_CASE(64, 3);
+  ATTN_CASE(64, 5);   // 192/16: 145 tokens
+#undef ATTN_CASE
+  return fail(SSP2_EINVAL, "attention kernel not instantiated for d_h=%d, tokens=%d", e->dh, e->tokens);
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int ssp2_abi_version(void) { return SSP2_ABI_VERSION; }
+const char* ssp2_last_error(void) { return g_err.c_str(); }
+
+int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
+  if (!desc || !out || !desc->d_int) return fail(SSP2_EINVAL, "null argument");
+  const ssp2_vit_desc& d = *desc;
+  if (d.img <= 0 || d.patch <= 0 || d.img % d.patch) return fail(SSP2_EINVAL, "img %d not divisible by patch %d", d.img, d.patch);
+  if (d.dim <= 0 || d.dim % 64 || d.dim > 2048) return fail(SSP2_EINVAL, "dim %d must be a multiple of 64, <= 2048", d.dim);
+  if (d.heads <= 0 || d.dim % d.heads) return fail(SSP2_EINVAL, "dim %d not divisible by heads %d", d.dim, d.heads);
+  if (d.depth <= 0 || d.classes <= 0 || d.max_images <= 0) return fail(SSP2_EINVAL, "depth/classes/max_images must be positive");
+  int dev_count = 0;
+  if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count == 0)
+    return fail(SSP2_EHIP, "no HIP device visible: libssp2vit has no CPU path");
+
+  auto* e = new ssp2_engine();
+  e->d = d;
+  e->d_int.assign(d.d_int, d.d_int + d.depth);
+  e->d.d_int = e->d_int.data();
+  e->side = d.img / d.patch;
+  e->patches = e->side * e->side;
+  e->tokens = e->patches + 1;
+  e->dh = d.dim / d.heads;
+  e->kpe = 3 * d.patch * d.patch;
+  e->kpe_pad = ceil_to(e->kpe, GEMM_BK);
+  if (!(e->dh == 16 || e->dh == 64 || e->dh == 80)) {
+    delete e;
+    return fail(SSP2_EINVAL, "head dim %d unsupported (16, 64, 80)", d.dim / d.heads);
+  }
+  int rc = 0;
+#define TRY(x) do { if ((rc = (x))) { ssp2_destroy(e); return rc; } } while (0)
+  TRY(mat_alloc(e, e->patch, d.dim, e->kpe));
+  TRY(mat_alloc(e, e->head, d.classes, d.dim));
+  TRY(dalloc(e, &e->cls, d.dim, false));
+  TRY(dalloc(e, &e->pos, (size_t)e->tokens * d.dim, false));
+  TRY(dalloc(e, &e->lnf_g, d.dim, false));
+  TRY(dalloc(e, &e->lnf_b, d.dim, false));
+  e->layers.resize(d.depth);
+  for (int l = 0; l < d.depth; ++l) {
+    Layer& L = e->layers[l];
+    L.d_int = e->d_int[l];
+    if (L.d_int <= 0) { ssp2_destroy(e); return fail(SSP2_EINVAL, "d_int[%d] = %d", l, L.d_int); }
+    L.ld_int = ceil_to(L.d_int, GEMM_BK);
+    e->ld_int_max = L.ld_int > e->ld_int_max ? L.ld_int : e->ld_int_max;
+    TRY(dalloc(e, &L.ln1_g, d.dim, false)); TRY(dalloc(e, &L.ln1_b, d.dim, false));
+    TRY(dalloc(e, &L.ln2_g, d.dim, false)); TRY(dalloc(e, &L.ln2_b, d.dim, false));
+    TRY(mat_alloc(e, L.qkv, 3 * d.dim, d.dim));
+    TRY(mat_alloc(e, L.proj, d.dim, d.dim));
+    TRY(mat_alloc(e, L.fc1, L.d_int, d.dim));
+    TRY(mat_alloc(e, L.fc2, d.dim, L.d_int));
+  }
+  const size_t M = (size_t)d.max_images * e->tokens;
+  const size_t tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
+  TRY(dalloc(e, &e->a_pe, (size_t)d.max_images * e->patches * e->kpe_pad, true));
+  TRY(dalloc(e, &e->hbuf, M * d.dim, true));
+  TRY(dalloc(e, &e->qkvbuf, M * 3 * d.dim, true));
+  TRY(dalloc(e, &e->obuf, M * d.dim, true));
+  TRY(dalloc(e, &e->actbuf, M * e->ld_int_max, true));
+  if (e->tokens < GEMM_BM) TRY(dalloc(e, &e->prebuf, M * e->ld_int_max, true));
+  TRY(dalloc(e, &e->slab, tiles_m * 2 * e->ld_int_max, true));
+  TRY(dalloc(e, &e->norms, (size_t)d.max_images * e->ld_int_max, true));
+  TRY(dalloc(e, &e->cls_h, (size_t)d.max_images * d.dim, true));
+  TRY(dalloc(e, &e->logits, (size_t)d.max_images * d.classes, true));
+#undef TRY
+  *out = e;
+  return 0;
+}
+
+int ssp2_destroy(ssp2_handle e) {
+  if (!e) return 0;
+  hipStreamSynchronize(e->stream);
+  for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  for (void* p : e->allocs) hipFree(p);
+  delete e;
+  return 0;
+}
+
+int ssp2_set_stream(ssp2_handle e, void* s) {
+  if (!e) return fail(SSP2_EINVAL, "null handle");
+  e->stream = (hipStream_t)s;
+  return 0;
+}
+
+int ssp2_tokens(ssp2_handle e) { return e ? e->tokens : SSP2_EINVAL; }
+size_t ssp2_workspace_bytes(ssp2_handle e) { return e ? e->ws_bytes : 0; }
+
+static int upload_matrix(Mat& m, const float* host, size_t numel) {
+  if (numel != (size_t)m.rows * m.cols) return fail(SSP2_EINVAL, "matrix expects %d x %d = %zu values, got %zu", m.rows, m.cols, (size_t)m.rows * m.cols, numel);
+  std::vector<uint16_t> tmp((size_t)m.rows_pad * m.ld, 0);
+  for (int r = 0; r < m.rows; ++r)
+    for (int c = 0; c < m.cols; ++c) tmp[(size_t)r * m.ld + c] = f2bf(host[(size_t)r * m.cols + c]);
+  HIPCHK(hipMemcpy(m.w, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+  m.w_set = true;
+  return 0;
+}
+static int upload_bias(Mat& m, const float* host, size_t numel) {
+  if (numel != (size_t)m.rows) return fail(SSP2_EINVAL, "bias expects %d values, got %zu", m.rows, numel);
+  std::vector<float> tmp(m.rows_pad, 0.f);
+  for (int r = 0; r < m.rows; ++r) tmp[r] = bf2f(f2bf(host[r]));   // autocast casts the bias to bf16 too
+  HIPCHK(hipMemcpy(m.b, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+  m.b_set = true;
+  return 0;
+}
+static int upload_f32(float* dst, const float* host, size_t numel, size_t expect, bool* flag) {
+  if (numel != expect) return fail(SSP2_EINVAL, "vector expects %zu values, got %zu", expect, numel);
+  HIPCHK(hipMemcpy(dst, host, numel * 4, hipMemcpyHostToDevice));
+  *flag = true;
+  return 0;
+}
+
+int ssp2_load_tensor(ssp2_handle e, int kind, int layer, const float* host, size_t numel) {
+  if (!e || !host) return fail(SSP2_EINVAL, "null argument");
+  const int D = e->d.dim;
+  const bool per_layer = kind >= SSP2_T_LN1_G && kind <= SSP2_T_FC2_B;
+  if (per_layer && (layer < 0 || layer >= e->d.depth)) return fail(SSP2_EINVAL, "layer %d out of range", layer);
+  Layer* L = per_layer ? &e->layers[layer] : nullptr;
+  switch (kind) {
+    case SSP2_T_PATCH_W: return upload_matrix(e->patch, host, numel);
+    case SSP2_T_PATCH_B: return upload_bias(e->patch, host, numel);
+    case SSP2_T_CLS: return upload_f32(e->cls, host, numel, D, &e->misc_set[0]);
+    case SSP2_T_POS: return upload_f32(e->pos, host, numel, (size_t)e->tokens * D, &e->misc_set[1]);
+    case SSP2_T_LN1_G: return upload_f32(L->ln1_g, host, numel, D, &L->ln_set[0]);
+    case SSP2_T_LN1_B: return upload_f32(L->ln1_b, host, numel, D, &L->ln_set[1]);
+    case SSP2_T_LN2_G: return upload_f32(L->ln2_g, host, numel, D, &L->ln_set[2]);
+    case SSP2_T_LN2_B: return upload_f32(L->ln2_b, host, numel, D, &L->ln_set[3]);
+    case SSP2_T_QKV_W: return upload_matrix(L->qkv, host, numel);
+    case SSP2_T_QKV_B: return upload_bias(L->qkv, host, numel);
+    case SSP2_T_PROJ_W: return upload_matrix(L->proj, host, numel);
+    case SSP2_T_PROJ_B: return upload_bias(L->proj, host, numel);
+    case SSP2_T_FC1_W: return upload_matrix(L->fc1, host, numel);
+    case SSP2_T_FC1_B: return upload_bias(L->fc1, host, numel);
+    case SSP2_T_FC2_W: return upload_matrix(L->fc2, host, numel);
+    case SSP2_T_FC2_B: return upload_bias(L->fc2, host, numel);
+    case SSP2_T_LNF_G: return upload_f32(e->lnf_g, host, numel, D, &e->misc_set[2]);
+    case SSP2_T_LNF_B: return upload_f32(e->lnf_b, host, numel, D, &e->misc_set[3]);
+    case SSP2_T_HEAD_W: return upload_matrix(e->head, host, numel);
+    case SSP2_T_HEAD_B: return upload_bias(e->head, host, numel);
+    default: return fail(SSP2_EINVAL, "unknown tensor kind %d", kind);
+  }
+}
+
+static int check_n(ssp2_engine* e, int n) {
+  if (!e) return fail(SSP2_EINVAL, "null handle");
+  if (n <= 0 || n > e->d.max_images) return fail(SSP2_ESTATE, "n=%d outside (0, max_images=%d]", n, e->d.max_images);
+  return 0;
+}
+
+int ssp2_embed(ssp2_handle e, const float* pixels_dev, int n, float* x_dev) {
+  int rc;
+  if ((rc = check_n(e, n))) return rc;
+  if (!pixels_dev || !x_dev) return fail(SSP2_EINVAL, "null device pointer");
+  if (!(e->patch.w_set && e->patch.b_set && e->misc_set[0] && e->misc_set[1])) return fail(SSP2_ESTATE, "patch/cls/pos weights not loaded");
+  const int D = e->d.dim;
+  {
+    ProfScope ps(e, SSP2_K_OTHER);
+    const long total = (long)n * e->patches * (e->kpe_pad / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(im2col_patch_kernel, dim3(blocks), dim3(256), 0, e->stream, pixels_dev, e->a_pe, n, e->d.img,
+                       e->d.patch, e->side, e->kpe, e->kpe_pad);
+    hipLaunchKernelGGL(cls_row_kernel, dim3((n * D + 255) / 256), dim3(256), 0, e->stream, x_dev, e->cls, e->pos, n, e->tokens, D);
+    HIPCHK(hipGetLastError());
+  }
+  GemmArgs g{};
+  g.A = e->a_pe; g.lda = e->kpe_pad; g.W = e->patch.w; g.ldw = e->patch.ld; g.bias = e->patch.b;
+  g.M = n * e->patches; g.N = D; g.K = e->kpe_pad; g.tiles_n = e->patch.rows_pad / GEMM_BN;
+  g.x = x_dev; g.ldx = D; g.pos = e->pos; g.patches = e->patches;
+  return launch_gemm<EPI_PATCH>(e, g, SSP2_K_GEMM_PATCH);
+}
+
+int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const uint8_t* attn_skip, int score_site,
+                int score_chain, float* batch_scores, int score_ld) {
+  int rc;
+  if ((rc = check_n(e, n))) return rc;
+  if (!x) return fail(SSP2_EINVAL, "null x");
+  if (l_begin < 0 || l_end > e->d.depth || l_begin > l_end) return fail(SSP2_EINVAL, "bad layer range [%d,%d)", l_begin, l_end);
+  if (score_site < 0 || score_site > 2) return fail(SSP2_EINVAL, "bad score_site %d", score_site);
+  if (score_site && (!batch_scores || score_ld < e->ld_int_max)) return fail(SSP2_EINVAL, "batch_scores needs ld >= %d", e->ld_int_max);
+  const int D = e->d.dim, M = n * e->tokens;
+  const bool fused = score_site && e->tokens >= GEMM_BM;   // a 128-row tile then spans at most two samples
+  for (int l = l_begin; l < l_end; ++l) {
+    Layer& L = e->layers[l];
+    const bool skip = attn_skip && attn_skip[l];
+    if (!(L.ln_set[2] && L.ln_set[3] && L.fc1.w_set && L.fc1.b_set && L.fc2.w_set && L.fc2.b_set))
+      return fail(SSP2_ESTATE, "layer %d MLP weights not loaded", l);
+    if (!skip) {
+      if (!(L.ln_set[0] && L.ln_set[1] && L.qkv.w_set && L.qkv.b_set && L.proj.w_set && L.proj.b_set))
+        return fail(SSP2_ESTATE, "layer %d attention weights not loaded", l);
+      if ((rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, e->hbuf, D, M, D))) return rc;
+      GemmArgs q{};
+      q.A = e->hbuf; q.lda = D; q.W = L.qkv.w; q.ldw = L.qkv.ld; q.bias = L.qkv.b;
+      q.M = M; q.N = 3 * D; q.K = D; q.tiles_n = L.qkv.rows_pad / GEMM_BN; q.out = e->qkvbuf; q.ldo = 3 * D;
+      if ((rc = launch_gemm<EPI_BF16>(e, q, SSP2_K_GEMM_QKV))) return rc;
+      if ((rc = launch_attn(e, n))) return rc;
+      GemmArgs p{};
+      p.A = e->obuf; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.bias = L.proj.b;
+      p.M = M; p.N = D; p.K = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = x; p.ldx = D;
+      if ((rc = launch_gemm<EPI_RESID>(e, p, SSP2_K_GEMM_PROJ))) return rc;
+    }
+    if ((rc = launch_ln(e, x, D, L.ln2_g, L.ln2_b, e->hbuf, D, M, D))) return rc;
+    GemmArgs f{};
+    f.A = e->hbuf; f.lda = D; f.W = L.fc1.w; f.ldw = L.fc1.ld; f.bias = L.fc1.b;
+    f.M = M; f.N = L.ld_int; f.K = D; f.tiles_n = L.fc1.rows_pad / GEMM_BN; f.out = e->actbuf; f.ldo = L.ld_int;
+    f.score_site = fused ? score_site : 0; f.tokens = e->tokens; f.slab = e->slab; f.slab_ld = L.ld_int;
+    // unfused pre-GELU scoring (models with < 128 tokens): the hook sees fc1's output, fc2 consumes the GELU
+    // of it, so the epilogue also stores the pre-activation for the standalone L2 kernel to read.
+    f.out2 = (score_site == SSP2_SCORE_PRE_GELU && !fused) ? e->prebuf : nullptr;
+    if ((rc = launch_gemm<EPI_FC1>(e, f, SSP2_K_GEMM_FC1))) return rc;
+    if (score_site) {
+      float* row = batch_scores + (size_t)l * score_ld;
+      if (fused) {
+        ProfScope ps(e, SSP2_K_SCORE_FINISH);
+        hipLaunchKernelGGL(score_norms_from_slab_kernel, dim3((L.ld_int + 255) / 256, n), dim3(256), 0, e->stream,
+                           e->slab, e->norms, n, e->tokens, L.ld_int, score_chain);
+        hipLaunchKernelGGL(score_colsum_kernel, dim3((L.ld_int + 255) / 256), dim3(256), 0, e->stream, e->norms, row, n, L.ld_int, score_chain);
+        HIPCHK(hipGetLastError());
+      } else {
+        const bf16* seen = (score_site == SSP2_SCORE_PRE_GELU) ? e->prebuf : e->actbuf;
+        ProfScope ps(e, SSP2_K_ACT_L2);
+        if ((rc = ssp2_act_l2_accum(e->stream, seen, 0, n, e->tokens, L.d_int, L.ld_int, score_chain, e->norms, row))) return rc;
+      }
+    }
+    GemmArgs o{};
+    o.A = e->actbuf; o.lda = L.ld_int; o.W = L.fc2.w; o.ldw = L.fc2.ld; o.bias = L.fc2.b;
+    o.M = M; o.N = D; o.K = L.ld_int; o.tiles_n = L.fc2.rows_pad / GEMM_BN; o.x = x; o.ldx = D;
+    if ((rc = launch_gemm<EPI_RESID>(e, o, SSP2_K_GEMM_FC2))) return rc;
+  }
+  return 0;
+}
+
+int ssp2_head(ssp2_handle e, const float* x, int n, float* logits_dev, int32_t* pred, const int64_t* labels, int64_t* correct) {
+  int rc;
+  if ((rc = check_n(e, n))) return rc;
+  if (!x) return fail(SSP2_EINVAL, "null x");
+  if (!(e->misc_set[2] && e->misc_set[3] && e->head.w_set && e->head.b_set)) return fail(SSP2_ESTATE, "final norm / head weights not loaded");
+  const int D = e->d.dim;
+  if ((rc = launch_ln(e, x, (size_t)e->tokens * D, e->lnf_g, e->lnf_b, e->cls_h, D, n, D))) return rc;
+  float* lg = logits_dev ? logits_dev : e->logits;
+  GemmArgs g{};
+  g.A = e->cls_h; g.lda = D; g.W = e->head.w; g.ldw = e->head.ld; g.bias = e->head.b;
+  g.M = n; g.N = e->d.classes; g.K = D; g.tiles_n = e->head.rows_pad / GEMM_BN; g.x = lg; g.ldx = e->d.classes;
+  if ((rc = launch_gemm<EPI_F32>(e, g, SSP2_K_GEMM_HEAD))) return rc;
+  if (pred || (labels && correct)) {
+    ProfScope ps(e, SSP2_K_OTHER);
+    hipLaunchKernelGGL(argmax_top1_kernel, dim3((n + 3) / 4), dim3(256), 0, e->stream, lg, n, e->d.classes, pred, labels,
+                       (unsigned long long*)correct);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+int ssp2_act_l2_accum(void* stream, const void* act, int dtype, int n, int tokens, int d, int ld, int chain, float* norms_ws, float* out) {
+  if (!act || !norms_ws || !out) return fail(SSP2_EINVAL, "null device pointer");
+  if (n <= 0 || tokens <= 0 || d <= 0 || ld < d || (ld % 8)) return fail(SSP2_EINVAL, "bad shape n=%d tokens=%d d=%d ld=%d (ld multiple of 8, >= d)", n, tokens, d, ld);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((ld + 511) / 512, n), blk(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(act_l2_norms_kernel<bf16>, grid, blk, 0, s, (const bf16*)act, norms_ws, tokens, ld, chain);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(act_l2_norms_kernel<float>, grid, blk, 0, s, (const float*)act, norms_ws, tokens, ld, chain);
+  else
+    return fail(SSP2_EINVAL, "dtype %d (0 = bf16, 1 = f32)", dtype);
+  hipLaunchKernelGGL(score_colsum_kernel, dim3((ld + 255) / 256), dim3(256), 0, s, norms_ws, out, n, ld, chain);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp2_profile_begin(ssp2_handle e, int klass) {
+  if (!e || klass < 0 || klass >= SSP2_K_COUNT) return fail(SSP2_EINVAL, "bad profile class");
+  for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  e->prof_events.clear();
+  e->prof_class = klass;
+  return 0;
+}
+
+int ssp2_profile_end(ssp2_handle e, double* total_ms, int64_t* launches) {
+  if (!e) return fail(SSP2_EINVAL, "null handle");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  double tot = 0;
+  for (auto& pr : e->prof_events) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+    tot += ms;
+    hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int64_t)e->prof_events.size();
+  e->prof_events.clear();
+  e->prof_class = -1;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,201 @@
+// Bandwidth-bound helper kernels: im2col for the patch-embed GEMM, LayerNorm, stage-1 score finishing,
+// the standalone activation-L2 kernel, argmax/top-1.
+#pragma once
+#include "common.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// im2col for conv k=s=p (a pure gather): pixels f32 NCHW [n,3,img,img] -> A bf16 [n*P, Kpad],
+// column = c*p*p + ky*p + kx (the flattened conv-weight order), zero-filled up to Kpad.
+// One thread per 8 output columns (16-B store); reads are contiguous runs of p floats.
+__global__ void im2col_patch_kernel(const float* __restrict__ px, bf16* __restrict__ out, int n, int img, int p,
+                                    int side, int K, int Kpad) {
+  const int chunks = Kpad / 8;
+  const long total = (long)n * side * side * chunks;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % chunks);
+    const long row = idx / chunks;
+    const int pp = (int)(row % (side * side));
+    const int im = (int)(row / (side * side));
+    const int py = pp / side, pxx = pp - py * side;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = ch * 8 + j;
+      float f = 0.f;
+      if (col < K) {
+        const int c = col / (p * p), rem = col - c * p * p;
+        const int ky = rem / p, kx = rem - ky * p;
+        f = px[(((size_t)im * 3 + c) * img + (py * p + ky)) * img + (pxx * p + kx)];
+      }
+      v[j] = (bf16)f;
+    }
+    *(bf16x8*)(out + row * Kpad + ch * 8) = v;
+  }
+}
+
+// x[img*N + 0] = cls + pos[0]   (fp32; the concat promotes to fp32 under autocast)
+__global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+                               int n, int tokens, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * dim) {
+    const int im = i / dim, d = i - im * dim;
+    x[(size_t)im * tokens * dim + d] = cls[d] + pos[d];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim: fp32 rows -> bf16 rows.  One wave per row, the row lives in registers
+// (two-pass mean / variance in fp32).  in row r is read at x + r*in_stride (in_stride = tokens*dim picks
+// the CLS rows for the classifier head).  D multiple of 64, D <= 64*MAXV.
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, size_t in_stride,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16* __restrict__ y,
+                                                            int out_ld, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * in_stride;
+  const int nv = D >> 6;
+  float v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) { v[i] = xr[i * 64 + lane]; s += v[i]; }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) { const float d = v[i] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  bf16* yr = y + (size_t)row * out_ld;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv) {
+      const int c = i * 64 + lane;
+      yr[c] = (bf16)((v[i] - mean) * rstd * gamma[c] + beta[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage-1 score, fused path, step 2: per-(sample, neuron) norm from the fc1 epilogue's slab.
+//   slab [tiles_m][2][ld]: tile t covers rows [128t, 128t+128); segment 0 = rows of sample floor(128t/N),
+//   segment 1 = rows of the following sample.  norms[s][j] = sqrt(sum of the segments that belong to s).
+__global__ void score_norms_from_slab_kernel(const float* __restrict__ slab, float* __restrict__ norms, int n,
+                                             int tokens, int ld, int chain) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  if (j >= ld) return;
+  const int t0 = (s * tokens) / 128, t1 = ((s + 1) * tokens - 1) / 128;
+  float acc = 0.f;
+  for (int t = t0; t <= t1; ++t) {
+    const int seg = ((t * 128) / tokens == s) ? 0 : 1;
+    acc += slab[((size_t)t * 2 + seg) * ld + j];
+  }
+  float nrm = sqrtf(acc);
+  if (chain) nrm = bf16_round(nrm);
+  norms[(size_t)s * ld + j] = nrm;
+}
+
+// step 3 (both paths): out[j] = sum_s norms[s][j], samples in index order (fixed association).
+__global__ void score_colsum_kernel(const float* __restrict__ norms, float* __restrict__ out, int n, int ld, int chain) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ld) return;
+  float acc = 0.f;
+  for (int s = 0; s < n; ++s) acc += norms[(size_t)s * ld + j];
+  out[j] = chain ? bf16_round(acc) : acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Standalone activation-L2 kernel (the hook body on an activation tensor resident in HBM) — HBM-bound.
+//   act [n, tokens, ld] (bf16 or f32) ; norms[s][j] = sqrt(sum_t act[s,t,j]^2)
+// grid (ld/512, n); 256 threads: wave w streams tokens w, w+4, ... ; lane owns 8 consecutive neurons
+// (one 16-B load per token row for bf16), 4 token rows in flight per wave; cross-wave fold through LDS.
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&f)[8]);
+template <>
+__device__ __forceinline__ void load8<bf16>(const bf16* p, float (&f)[8]) {
+  const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) f[k] = (float)v[k];
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&f)[8]) {
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { f[k] = a[k]; f[4 + k] = b[k]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__ act, float* __restrict__ norms,
+                                                          int tokens, int ld, int chain) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.y;
+  const int col = blockIdx.x * 512 + lane * 8;
+  const bool ok = col < ld;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  if (ok) {
+    const T* base = act + (size_t)s * tokens * ld + col;
+    int t = wave;
+    for (; t + 12 < tokens; t += 16) {
+      float f0[8], f1[8], f2[8], f3[8];
+      load8<T>(base + (size_t)t * ld, f0);
+      load8<T>(base + (size_t)(t + 4) * ld, f1);
+      load8<T>(base + (size_t)(t + 8) * ld, f2);
+      load8<T>(base + (size_t)(t + 12) * ld, f3);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += f0[k] * f0[k] + f1[k] * f1[k] + f2[k] * f2[k] + f3[k] * f3[k];
+    }
+    for (; t < tokens; t += 4) {
+      float f0[8];
+      load8<T>(base + (size_t)t * ld, f0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += f0[k] * f0[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = acc[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    if (blockIdx.x * 512 + c < ld) {
+      float nrm = sqrtf((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+      if (chain) nrm = bf16_round(nrm);
+      norms[(size_t)s * ld + blockIdx.x * 512 + c] = nrm;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-1: one wave per image; first-max-index rule (torch.argmax: lowest index among equal maxima; NaN
+// counts as maximal, as torch does).  correct += (pred == label) with an integer atomic (exact, order-free).
+__global__ __launch_bounds__(256) void argmax_top1_kernel(const float* __restrict__ logits, int n, int classes,
+                                                         int32_t* __restrict__ pred, const int64_t* __restrict__ labels,
+                                                         unsigned long long* __restrict__ correct) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* lr = logits + (size_t)row * classes;
+  float best = -INFINITY; int bi = 0x7fffffff; bool bnan = false;
+  for (int c = lane; c < classes; c += 64) {
+    const float v = lr[c];
+    const bool vnan = v != v;
+    if (vnan) { bnan = true; bi = c; break; }            // first NaN wins for this lane (lowest index first)
+    if (v > best || bi == 0x7fffffff) { best = v; bi = c; }   // strict >: lowest index among equals
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o); const int on = __shfl_xor((int)bnan, o);
+    bool take;
+    if (bnan != (bool)on) take = (bool)on;               // NaN beats non-NaN
+    else if (bnan) take = oi < bi;                       // both NaN: lower index
+    else take = (ob > best) || (ob == best && oi < bi);
+    if (take) { best = ob; bi = oi; bnan = (bool)on; }
+  }
+  if (lane == 0) {
+    if (pred) pred[row] = bi;
+    if (labels && correct && labels[row] == (int64_t)bi) atomicAdd(correct, 1ULL);
+  }
+}

@@ -1,0 +1,100 @@
+"""ctypes binding of libssp2vit.so (include/ssp2vit.h).  No compute happens here and there is no fallback:
+if the shared library (or a GPU) is missing the product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)                       # 2ssp-x-vit_amd/
+CSRC = os.path.join(PKG_ROOT, "csrc")
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libssp2vit.so")
+INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
+
+# every symbol include/ssp2vit.h declares
+SYMBOLS = [
+    "ssp2_abi_version", "ssp2_last_error", "ssp2_create", "ssp2_destroy", "ssp2_set_stream", "ssp2_load_tensor",
+    "ssp2_embed", "ssp2_layers", "ssp2_head", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
+    "ssp2_tokens", "ssp2_workspace_bytes",
+]
+
+T_KINDS = ["patch_w", "patch_b", "cls", "pos", "ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+           "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "lnf_g", "lnf_b", "head_w", "head_b"]
+SCORE_SITE = {"none": 0, "pre_gelu": 1, "post_gelu": 2}
+SCORE_CHAIN = {"fp32": 0, "bf16_ref": 1}
+K_CLASS = {"gemm_fc1": 0, "gemm_fc2": 1, "gemm_qkv": 2, "gemm_proj": 3, "gemm_patch": 4, "gemm_head": 5,
+           "attn": 6, "ln": 7, "score_finish": 8, "act_l2": 9, "other": 10}
+
+
+class VitDesc(C.Structure):
+    _fields_ = [("img", C.c_int32), ("patch", C.c_int32), ("dim", C.c_int32), ("heads", C.c_int32),
+                ("depth", C.c_int32), ("classes", C.c_int32), ("ln_eps", C.c_float), ("max_images", C.c_int32),
+                ("d_int", C.POINTER(C.c_int32))]
+
+
+class Ssp2Error(RuntimeError):
+    pass
+
+
+def build_library(verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Output stays in-tree: 2ssp-x-vit_amd/lib/."""
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           os.path.join(CSRC, "engine.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+def _needs_rebuild() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "ssp2vit.h")]
+    return any(os.path.getmtime(s) > t for s in srcs if os.path.isfile(s))
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if _needs_rebuild():
+        if not build_if_missing:
+            raise Ssp2Error(f"{LIB_PATH} missing or stale; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        build_library()
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64p = C.c_void_p, C.c_int, C.POINTER(C.c_int64)
+    lib.ssp2_abi_version.restype = i32
+    lib.ssp2_last_error.restype = C.c_char_p
+    lib.ssp2_create.argtypes = [C.POINTER(VitDesc), C.POINTER(vp)]
+    lib.ssp2_destroy.argtypes = [vp]
+    lib.ssp2_set_stream.argtypes = [vp, vp]
+    lib.ssp2_load_tensor.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.c_size_t]
+    lib.ssp2_embed.argtypes = [vp, vp, i32, vp]
+    lib.ssp2_layers.argtypes = [vp, vp, i32, i32, i32, C.POINTER(C.c_uint8), i32, i32, vp, i32]
+    lib.ssp2_head.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    lib.ssp2_act_l2_accum.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.ssp2_profile_begin.argtypes = [vp, i32]
+    lib.ssp2_profile_end.argtypes = [vp, C.POINTER(C.c_double), i64p]
+    lib.ssp2_tokens.argtypes = [vp]
+    lib.ssp2_workspace_bytes.argtypes = [vp]
+    lib.ssp2_workspace_bytes.restype = C.c_size_t
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("ssp2_last_error", "ssp2_workspace_bytes"):
+            fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().ssp2_last_error()
+        raise Ssp2Error(f"libssp2vit error {rc}: {msg.decode() if msg else '?'}")

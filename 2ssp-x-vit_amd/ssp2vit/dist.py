@@ -1,0 +1,66 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, weights replicated, calibration /
+eval BATCHES dealt round-robin (batch i -> rank i % P), no collective inside the forward.
+
+Exchange steps (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests):
+  * stage 1: ONE all_gather of the per-batch score vectors [n_local_batches, L, ld] (B/16: 147 KB per batch).
+    Every rank then adds the batch vectors in GLOBAL batch order, so the scores — and therefore the masks —
+    are bit-identical for every world size (a plain all-reduce would change the summation order with P).
+  * stage 2: ONE all_reduce(sum) of the int64 correct-counts [L+1] (+ total), exact.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+
+def world(group=None) -> Tuple[int, int]:
+    """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def owns(batch_index: int, rank: int, world_size: int) -> bool:
+    return batch_index % world_size == rank
+
+
+def gather_batch_vectors(local: Sequence[Tuple[int, torch.Tensor]], n_batches_total: int, group=None) -> List[torch.Tensor]:
+    """local = [(global batch index, tensor [L, ld])] owned by this rank (round-robin ownership).
+    Returns the vectors of ALL batches in global batch order, identical on every rank."""
+    import torch.distributed as dist
+    rank, ws = world(group)
+    if ws == 1:
+        return [v for _, v in sorted(local, key=lambda p: p[0])]
+    if n_batches_total == 0:
+        return []
+    slots = (n_batches_total + ws - 1) // ws
+    proto = local[0][1] if local else None
+    shape = torch.tensor(list(proto.shape) if proto is not None else [0, 0], dtype=torch.int64,
+                         device=proto.device if proto is not None else _default_device(group))
+    dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=group)          # ranks without a batch learn the shape
+    L, ld = int(shape[0]), int(shape[1])
+    dev = proto.device if proto is not None else _default_device(group)
+    mine = torch.zeros(slots, L, ld, dtype=torch.float32, device=dev)
+    for idx, v in local:
+        assert idx % ws == rank, "batch not owned by this rank"
+        mine[idx // ws].copy_(v)
+    everyone = [torch.empty_like(mine) for _ in range(ws)]
+    dist.all_gather(everyone, mine, group=group)
+    return [everyone[i % ws][i // ws] for i in range(n_batches_total)]
+
+
+def all_reduce_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
+    """int64 tensor, summed over ranks in place (exact)."""
+    import torch.distributed as dist
+    _, ws = world(group)
+    if ws > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    return counts
+
+
+def _default_device(group=None) -> torch.device:
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")

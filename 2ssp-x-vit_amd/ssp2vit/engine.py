@@ -1,0 +1,171 @@
+"""VitEngine: thin object wrapper over the C ABI.  PyTorch is used here only as plumbing — device buffers,
+the current HIP stream, and (elsewhere) torch.distributed; every arithmetic step of the hot path runs in
+libssp2vit's HIP kernels.  There is no CPU path: constructing an engine without a GPU raises."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import K_CLASS, SCORE_CHAIN, SCORE_SITE, T_KINDS, Ssp2Error, VitDesc, check
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class VitEngine:
+    def __init__(self, weights: Dict, device: str | torch.device = "cuda:0", max_images: int = 64):
+        if not torch.cuda.is_available():
+            raise Ssp2Error("ssp2vit needs an MI355X (HIP device): there is no CPU fallback in the product path")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise Ssp2Error(f"ssp2vit runs on HIP devices only, got device={device!r}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = _lib.load()
+        self.depth = int(weights["depth"])
+        self.dim = int(weights["dim"])
+        self.classes = int(weights["classes"])
+        self.img = int(weights["img"])
+        self.d_int = [int(weights[f"fc1_w.{i}"].shape[0]) for i in range(self.depth)]
+        self.score_ld = max((d + 63) // 64 * 64 for d in self.d_int)
+        self.max_images = int(max_images)
+        self.absent = [bool(weights.get(f"attn_absent.{i}", False)) for i in range(self.depth)]
+        arr = (C.c_int32 * self.depth)(*self.d_int)
+        desc = VitDesc(self.img, int(weights["patch"]), self.dim, int(weights["heads"]), self.depth, self.classes,
+                       float(weights.get("eps", 1e-6)), self.max_images, arr)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.ssp2_create(C.byref(desc), C.byref(h)))
+            self.h = h
+            self.tokens = self.lib.ssp2_tokens(self.h)
+            self._load(weights)
+
+    # ------------------------------------------------------------------ weights
+    def _load(self, w: Dict) -> None:
+        def put(kind: str, layer: int, t: torch.Tensor):
+            t = t.detach().to("cpu", torch.float32).contiguous()
+            check(self.lib.ssp2_load_tensor(self.h, T_KINDS.index(kind), layer,
+                                            C.cast(t.data_ptr(), C.POINTER(C.c_float)), t.numel()))
+        for k in ("patch_w", "patch_b", "cls", "pos", "lnf_g", "lnf_b", "head_w", "head_b"):
+            put(k, 0, w[k])
+        for i in range(self.depth):
+            for k in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_g", "ln2_b",
+                      "fc1_w", "fc1_b", "fc2_w", "fc2_b"):
+                put(k, i, w[f"{k}.{i}"])
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.ssp2_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def _bind_stream(self) -> None:
+        check(self.lib.ssp2_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def _skip_array(self, attn_skip: Optional[Sequence[int]]):
+        flags = [1 if a else 0 for a in self.absent]
+        if attn_skip is not None:
+            for i in attn_skip:
+                flags[int(i)] = 1
+        if not any(flags):
+            return None
+        return (C.c_uint8 * self.depth)(*flags)
+
+    def new_x(self, n: int) -> torch.Tensor:
+        return torch.empty(n * self.tokens, self.dim, dtype=torch.float32, device=self.device)
+
+    def new_scores(self) -> torch.Tensor:
+        return torch.zeros(self.depth, self.score_ld, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ the four device entry points
+    def embed(self, pixels: torch.Tensor, x: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if pixels.dim() != 4 or pixels.shape[1] != 3 or pixels.shape[2] != self.img or pixels.shape[3] != self.img:
+            raise ValueError(f"pixel_values must be [n,3,{self.img},{self.img}], got {tuple(pixels.shape)}")
+        px = pixels.to(self.device, torch.float32, non_blocking=True).contiguous()
+        n = px.shape[0]
+        x = self.new_x(n) if x is None else x
+        self._bind_stream()
+        check(self.lib.ssp2_embed(self.h, _ptr(px), n, _ptr(x)))
+        return x
+
+    def layers(self, x: torch.Tensor, n: int, l_begin: int = 0, l_end: Optional[int] = None,
+               attn_skip: Optional[Sequence[int]] = None, score_site: str = "none", score_chain: str = "fp32",
+               batch_scores: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        l_end = self.depth if l_end is None else l_end
+        site = SCORE_SITE[score_site]
+        if site and batch_scores is None:
+            batch_scores = self.new_scores()
+        self._bind_stream()
+        check(self.lib.ssp2_layers(self.h, _ptr(x), n, l_begin, l_end, self._skip_array(attn_skip), site,
+                                   SCORE_CHAIN[score_chain], _ptr(batch_scores if site else None), self.score_ld))
+        return batch_scores if site else None
+
+    def head(self, x: torch.Tensor, n: int, labels: Optional[torch.Tensor] = None,
+             correct: Optional[torch.Tensor] = None, want_logits: bool = False, want_pred: bool = False):
+        logits = torch.empty(n, self.classes, dtype=torch.float32, device=self.device) if want_logits else None
+        pred = torch.empty(n, dtype=torch.int32, device=self.device) if want_pred else None
+        if labels is not None:
+            labels = labels.to(self.device, torch.int64, non_blocking=True).contiguous()
+            if correct is None:
+                correct = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._bind_stream()
+        check(self.lib.ssp2_head(self.h, _ptr(x), n, _ptr(logits), _ptr(pred), _ptr(labels),
+                                 _ptr(correct if labels is not None else None)))
+        return logits, pred, correct
+
+    def act_l2_accum(self, act: torch.Tensor, score_chain: str = "fp32") -> torch.Tensor:
+        """Standalone hook-body kernel: act [n, tokens, d] (bf16 or f32, contiguous, d % 8 == 0) -> f32 [d]."""
+        if act.dim() != 3 or not act.is_contiguous() or act.device.type != "cuda":
+            raise ValueError("act must be a contiguous [n, tokens, d] device tensor")
+        n, t, d = act.shape
+        dtype = {torch.bfloat16: 0, torch.float32: 1}[act.dtype]
+        ws = torch.empty(n, d, dtype=torch.float32, device=act.device)
+        out = torch.empty(d, dtype=torch.float32, device=act.device)
+        check(self.lib.ssp2_act_l2_accum(C.c_void_p(torch.cuda.current_stream(act.device).cuda_stream), _ptr(act), dtype,
+                                         n, t, d, d, SCORE_CHAIN[score_chain], _ptr(ws), _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ compositions used by the host API
+    def forward_scores(self, pixels: torch.Tensor, score_site: str, score_chain: str = "fp32") -> torch.Tensor:
+        """One calibration batch: returns f32 [depth, score_ld], row l = sum over the batch's samples of the
+        per-sample token-L2 of block l's FFN activation (reference hook body, src/vit_pruning.py:151-152)."""
+        n = pixels.shape[0]
+        if n > self.max_images:   # one canonical batch per call keeps the sample order of the sum fixed
+            raise Ssp2Error(f"batch of {n} images exceeds engine capacity {self.max_images}")
+        x = self.embed(pixels)
+        return self.layers(x, n, 0, self.depth, None, score_site, score_chain)
+
+    def forward_logits(self, pixels: torch.Tensor, attn_skip: Optional[Sequence[int]] = None) -> torch.Tensor:
+        outs = []
+        for s in range(0, pixels.shape[0], self.max_images):
+            chunk = pixels[s:s + self.max_images]
+            x = self.embed(chunk)
+            self.layers(x, chunk.shape[0], 0, self.depth, attn_skip)
+            outs.append(self.head(x, chunk.shape[0], want_logits=True)[0])
+        return torch.cat(outs, 0)
+
+    def profile(self, klass: str):
+        eng = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                eng._bind_stream()
+                check(eng.lib.ssp2_profile_begin(eng.h, K_CLASS[klass]))
+                return self_inner
+
+            def __exit__(self_inner, *exc):
+                ms, cnt = C.c_double(), C.c_int64()
+                check(eng.lib.ssp2_profile_end(eng.h, C.byref(ms), C.byref(cnt)))
+                self_inner.total_ms, self_inner.launches = ms.value, cnt.value
+                return False
+        return _Ctx()

@@ -1,0 +1,489 @@
+"""Host-side mirror of the reference's function API (/root/reference/src/vit_pruning.py `__all__`, :10-21):
+same names, argument meaning, return types and error behaviour — but the two hot loops (stage-1 activation
+scoring, stage-2 attention-removal search) run on the MI355X through libssp2vit instead of calling
+`model(px)` under autocast.
+
+What stays on the host, unchanged in meaning (SURVEY.md §1 "seams"): the mask step on the final 12x3072 score
+vectors (same `torch.argsort` call, so equal scores give equal masks), the in-place weight slicing of the user's
+module, module surgery for the attention bypass, and the planner arithmetic.
+
+Extra keyword-only arguments (not in the reference): `score_chain`, `process_group`, `engine`.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import dist as _dist
+from . import weights as _weights
+from .planner import ModelStats, TwoSSPPlan, plan_from_stats
+
+__all__ = [
+    "prune_vit_mlp_width", "evaluate_top1", "prune_vit_attention_blocks", "plan_2ssp_allocation",
+    "count_total_params", "count_block_params", "compute_actual_sparsity", "save_report", "TwoSSPPlan",
+]
+
+
+# ----------------------------------------------------------------------------- anatomy (reference :27-75)
+def _get_encoder(vit_model):
+    base = getattr(vit_model, "vit", None)
+    if base is None:
+        base = getattr(vit_model, "base_model", None) or vit_model
+    return base.encoder if hasattr(base, "encoder") else base
+
+
+def _blocks(vit_model):
+    enc = _get_encoder(vit_model)
+    if hasattr(enc, "layer"):
+        return list(enc.layer), "hf"
+    if hasattr(enc, "blocks"):
+        return list(enc.blocks), "timm"
+    raise AttributeError("Unsupported ViT model structure: expected encoder.layer or blocks")
+
+
+def _gather_mlp_pairs(vit_model) -> List[Tuple[nn.Linear, nn.Linear]]:
+    blocks, kind = _blocks(vit_model)
+    if kind == "hf":
+        return [(b.intermediate.dense, b.output.dense) for b in blocks]
+    return [(b.mlp.fc1, b.mlp.fc2) for b in blocks]
+
+
+def _get_hidden_and_inter_sizes(vit_model) -> Tuple[int, List[int]]:
+    pairs = _gather_mlp_pairs(vit_model)
+    hidden = pairs[0][0].weight.size(1) if pairs else getattr(vit_model.config, "hidden_size", None)
+    return hidden, [p[0].weight.size(0) for p in pairs]
+
+
+def count_total_params(model: nn.Module) -> int:
+    return sum(p.numel() for p in model.parameters())
+
+
+def count_block_params(model: nn.Module) -> List[int]:
+    return [sum(p.numel() for p in b.parameters()) for b in _blocks(model)[0]]
+
+
+def compute_actual_sparsity(before_params: int, after_params: int) -> float:
+    return 0.0 if before_params <= 0 else (before_params - after_params) / before_params
+
+
+def _attn_module(block, kind):
+    return getattr(block, "attention" if kind == "hf" else "attn", None)
+
+
+def _model_stats(vit_model) -> ModelStats:
+    blocks, kind = _blocks(vit_model)
+    hidden, inters = _get_hidden_and_inter_sizes(vit_model)
+    attn = []
+    for b in blocks:
+        a = _attn_module(b, kind)
+        attn.append(0 if a is None else sum(p.numel() for p in a.parameters()))
+    ffn = [sum(p.numel() for p in i.parameters()) + sum(p.numel() for p in o.parameters())
+           for i, o in _gather_mlp_pairs(vit_model)]
+    return ModelStats(count_total_params(vit_model), hidden, inters, attn, ffn)
+
+
+def plan_2ssp_allocation(vit_model, target_sparsity: float, min_remaining: int = 256,
+                         forced_blocks: Optional[int] = None) -> TwoSSPPlan:
+    """Reference :585-769.  Pure host arithmetic on parameter counts."""
+    st = _model_stats(vit_model)
+    if st.hidden is None or len(st.inter_sizes) != len(count_block_params(vit_model)):
+        raise RuntimeError("Unable to determine hidden/intermediate sizes for planning.")
+    return plan_from_stats(st, target_sparsity, min_remaining, forced_blocks)
+
+
+# ----------------------------------------------------------------------------- engine cache
+_ENGINES: Dict[int, Tuple[Tuple, Any]] = {}
+
+
+def _fingerprint(model) -> Tuple:
+    return tuple((id(p), p._version, tuple(p.shape)) for p in model.parameters()) + \
+           tuple(type(m).__name__ for m in model.modules())
+
+
+def engine_for(model, device="cuda", max_images: int = 64):
+    """Build (or reuse) the HIP engine holding `model`'s current weights.  Raises without a GPU."""
+    from .engine import VitEngine
+    key = id(model)
+    fp = _fingerprint(model)
+    hit = _ENGINES.get(key)
+    if hit is not None and hit[0] == fp and hit[1].max_images >= max_images:
+        return hit[1]
+    if hit is not None:
+        hit[1].close()
+    dev = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}") \
+        if torch.cuda.is_available() else torch.device(device)
+    eng = VitEngine(_weights.from_module(model), device=dev, max_images=max(int(max_images), 1))
+    eng.layout = _weights.detect_layout(model)
+    _ENGINES[key] = (fp, eng)
+    return eng
+
+
+def release_engines() -> None:
+    for _, (_, e) in list(_ENGINES.items()):
+        e.close()
+    _ENGINES.clear()
+
+
+def _iter_limited(dataloader: Iterable, limit: Optional[int], progress: bool, desc: str):
+    it = dataloader
+    if progress:
+        try:
+            from tqdm.auto import tqdm
+            it = tqdm(dataloader, total=limit, desc=desc, leave=False)
+        except Exception:
+            pass
+    for i, batch in enumerate(it):
+        if limit is not None and i >= limit:
+            break
+        yield i, batch
+
+
+# ----------------------------------------------------------------------------- a1/a2 stage-1 scores
+@torch.no_grad()
+def _compute_ffn_activation_importance(vit_model, dataloader, device: str = "cuda", batch_limit: Optional[int] = None,
+                                       progress: bool = False, *, score_chain: str = "fp32", process_group=None,
+                                       engine=None) -> List[torch.Tensor]:
+    """Reference :111-201 — mean over calibration samples of the per-sample token-L2 of every block's FFN
+    intermediate activation (pre-GELU for timm-layout models, post-GELU for HF-layout ones).
+
+    Returns List[L] of CPU tensors [d_int]: float32 with score_chain="fp32" (default; fp32 accumulators end to
+    end), bfloat16 with score_chain="bf16_ref" (the reference's CPU-autocast rounding points)."""
+    vit_model.eval()
+    blocks, kind = _blocks(vit_model)           # raises AttributeError on unknown anatomy like the reference
+    d_ints = [p[0].out_features for p in _gather_mlp_pairs(vit_model)]
+    site = _weights.score_site_for("timm" if kind == "timm" else "hf")
+    rank, ws = _dist.world(process_group)
+
+    local: List[Tuple[int, torch.Tensor]] = []
+    seen = torch.zeros(2, dtype=torch.int64)    # [samples over ALL batches, number of batches]
+    eng = engine
+    for i, batch in _iter_limited(dataloader, batch_limit, progress, "S1 activations"):
+        px = batch["pixel_values"]
+        seen[0] += int(px.size(0)); seen[1] += 1
+        if not _dist.owns(i, rank, ws):
+            continue
+        if eng is None or (engine is None and px.size(0) > eng.max_images):
+            eng = engine_for(vit_model, device, max_images=max(64, int(px.size(0))))
+        local.append((i, eng.forward_scores(px, site, score_chain)))
+
+    n_batches, n_samples = int(seen[1]), int(seen[0])
+    vecs = _dist.gather_batch_vectors(local, n_batches, process_group)
+    denom = max(1, n_samples)
+    imps: List[torch.Tensor] = []
+    if not vecs:
+        return [torch.zeros(d) for d in d_ints]
+    if score_chain == "fp32":
+        total = torch.zeros_like(vecs[0])
+        for v in vecs:                          # global batch order: identical on every rank / world size
+            total += v
+        total = (total / denom).to("cpu")
+        return [total[l, :d].clone() for l, d in enumerate(d_ints)]
+    # bf16_ref: the cross-batch `+=` and the final division happen in bf16 exactly as reference :154-157, :200
+    host = [v.to("cpu") for v in vecs]
+    for l, d in enumerate(d_ints):
+        run = None
+        for v in host:
+            acc = v[l, :d].to(torch.bfloat16)   # exact: the kernel already rounded the batch sum to bf16
+            if run is None:
+                run = acc.clone()
+            else:
+                run += acc
+        imps.append(run / denom)
+    return imps
+
+
+# ----------------------------------------------------------------------------- a7/a8 width prune (host consumer)
+@torch.no_grad()
+def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: str = "l1", min_remaining: int = 256,
+                        n_to_prune_per_block: Optional[List[int]] = None, dataloader=None, device: str = "cuda",
+                        batch_limit: Optional[int] = None, progress: bool = False, collect_masks: bool = False,
+                        precomputed_importance: Optional[List[torch.Tensor]] = None, *, score_chain: str = "fp32",
+                        process_group=None):
+    """Reference :203-319.  Scores come from the HIP engine (strategy "act_l2"), a caller, or fc1 row-L1; the
+    keep-set is `sort(argsort(imp, descending=True)[:n-n_prune])`; the module is sliced in place and returned."""
+    pairs = _gather_mlp_pairs(vit_model)
+    if n_to_prune_per_block is not None:
+        if len(n_to_prune_per_block) != len(pairs):
+            raise ValueError("n_to_prune_per_block length must match number of blocks")
+    else:
+        if sparsity is None:
+            raise ValueError("Provide either sparsity or n_to_prune_per_block")
+        if not (0.0 <= sparsity < 1.0):
+            raise AssertionError("sparsity must be in [0,1)")
+
+    scores: Optional[List[torch.Tensor]] = None
+    if precomputed_importance is not None:
+        if len(precomputed_importance) != len(pairs):
+            raise ValueError("precomputed_importance length must match number of blocks")
+        scores = precomputed_importance
+    elif strategy == "act_l2" and dataloader is not None:
+        scores = _compute_ffn_activation_importance(vit_model, dataloader, device=device, batch_limit=batch_limit,
+                                                    progress=progress, score_chain=score_chain,
+                                                    process_group=process_group)
+
+    all_idx: List[List[int]] = []
+    all_masks: List[List[int]] = []
+    for b, (fc1, fc2) in enumerate(pairs):
+        w1, b1, w2 = fc1.weight, fc1.bias, fc2.weight
+        width = w1.size(0)
+        if scores is not None:
+            imp = scores[b].to(w1.device)
+            if imp.numel() != width:
+                raise RuntimeError("precomputed/act_l2 importance size mismatch with intermediate width")
+        elif strategy == "l1":
+            imp = w1.abs().sum(dim=1)
+        elif strategy == "act_l2":
+            raise RuntimeError("act_l2 importance requested but no dataloader/importance available")
+        else:
+            raise ValueError(f"Unknown strategy {strategy}")
+        drop = int(n_to_prune_per_block[b]) if n_to_prune_per_block is not None else int(width * sparsity)
+        if width - drop < min_remaining:
+            drop = max(0, width - min_remaining)
+        if drop <= 0:
+            continue
+        keep, _ = torch.sort(torch.argsort(imp, descending=True)[: width - drop])
+        mask = torch.ones(width, dtype=torch.int16, device=keep.device)
+        mask[keep] = 0                                     # 1 = prune, 0 = keep
+        if collect_masks:
+            all_masks.append(mask.cpu().tolist())
+            all_idx.append(torch.nonzero(mask == 1).view(-1).tolist())
+        fc1.weight = nn.Parameter(w1[keep].clone())
+        if b1 is not None:
+            fc1.bias = nn.Parameter(b1[keep].clone())
+        fc1.out_features = int(keep.numel())
+        fc1.in_features = w1.size(1)
+        fc2.weight = nn.Parameter(w2[:, keep].clone())
+        fc2.in_features = int(keep.numel())
+    if collect_masks:
+        return {"model": vit_model, "ffn_pruned_indices": all_idx, "ffn_prune_masks": all_masks}
+    return vit_model
+
+
+# ----------------------------------------------------------------------------- a4 top-1
+@torch.no_grad()
+def _top1_counts(model, dataloader, device="cuda", max_batches=None, progress=False, *, process_group=None,
+                 engine=None, attn_skip: Optional[Sequence[int]] = None) -> Tuple[int, int]:
+    rank, ws = _dist.world(process_group)
+    eng = engine
+    correct_dev = None
+    total = 0
+    for i, batch in _iter_limited(dataloader, max_batches, progress, "eval"):
+        if not _dist.owns(i, rank, ws):
+            continue
+        px, labels = batch["pixel_values"], batch["labels"]
+        if eng is None:
+            eng = engine_for(model, device, max_images=max(64, int(px.size(0))))
+        if correct_dev is None:
+            correct_dev = torch.zeros(1, dtype=torch.int64, device=eng.device)
+        for s in range(0, px.size(0), eng.max_images):
+            chunk = px[s:s + eng.max_images]
+            x = eng.embed(chunk)
+            eng.layers(x, chunk.size(0), 0, eng.depth, attn_skip)
+            eng.head(x, chunk.size(0), labels=labels[s:s + eng.max_images], correct=correct_dev)
+        total += int(labels.size(0))
+    counts = torch.tensor([0, total], dtype=torch.int64, device=correct_dev.device if correct_dev is not None else "cpu")
+    if correct_dev is not None:
+        counts[0] = correct_dev[0]
+    if ws > 1:
+        counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
+    c = counts.to("cpu")
+    return int(c[0]), int(c[1])
+
+
+@torch.no_grad()
+def evaluate_top1(model, dataloader, device: str = "cuda", max_batches: int | None = None, progress: bool = False,
+                  *, process_group=None, engine=None):
+    """Reference :325-373 — returns correct / max(1, total) as a Python float."""
+    model.eval()
+    c, t = _top1_counts(model, dataloader, device, max_batches, progress, process_group=process_group, engine=engine)
+    return c / max(1, t)
+
+
+# ----------------------------------------------------------------------------- a5 stage-2 search
+@torch.no_grad()
+def depth_search_counts(model, dataloader, device="cuda", batch_limit: Optional[int] = 5, *, process_group=None,
+                        engine=None, removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None):
+    """One pass over the eval batches that yields the baseline AND every candidate's correct-count.
+
+    The reference deep-copies the model and re-runs the whole forward per candidate (mask_conjunction.py:339-355,
+    src/vit_pruning.py:477-494).  Here the residual stream entering each block is cached during the baseline
+    forward, and candidate i (attention of block i bypassed) restarts from the cached input of block i: blocks
+    0..i-1 are bit-identical to the baseline, so the result equals a full re-run while executing
+    L(L+1)/2 + L block passes per batch instead of L(L+1).
+    Returns (baseline_correct, [candidate_correct], total)."""
+    rank, ws = _dist.world(process_group)
+    eng = engine
+    L = None
+    counts_dev = None
+    total = 0
+    removed = sorted(set(int(r) for r in removed))
+    for i, batch in _iter_limited(dataloader, batch_limit, False, "attn search"):
+        if not _dist.owns(i, rank, ws):
+            continue
+        px_all, labels_all = batch["pixel_values"], batch["labels"]
+        if eng is None:
+            eng = engine_for(model, device, max_images=max(64, int(px_all.size(0))))
+        L = eng.depth
+        cands = list(range(L)) if candidates is None else [int(c) for c in candidates]
+        if counts_dev is None:
+            counts_dev = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
+        for s in range(0, px_all.size(0), eng.max_images):
+            px = px_all[s:s + eng.max_images]
+            labels = labels_all[s:s + eng.max_images].to(eng.device)
+            n = px.size(0)
+            x = eng.embed(px)
+            cache = {}
+            first = min(cands) if cands else L
+            for l in range(L):
+                if l >= first and l in cands:
+                    cache[l] = x.clone()
+                eng.layers(x, n, l, l + 1, removed)
+            eng.head(x, n, labels=labels, correct=counts_dev[L:L + 1])
+            for c in cands:
+                xc = cache.pop(c)
+                eng.layers(xc, n, c, L, removed + [c])
+                eng.head(xc, n, labels=labels, correct=counts_dev[c:c + 1])
+        total += int(labels_all.size(0))
+    if counts_dev is None:
+        L = len(_blocks(model)[0]) if L is None else L
+        counts = torch.zeros(L + 2, dtype=torch.int64)
+    else:
+        counts = torch.cat([counts_dev, torch.tensor([total], dtype=torch.int64, device=counts_dev.device)])
+    if ws > 1:
+        counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
+    c = counts.to("cpu").tolist()
+    return c[-2], c[:-2], c[-1]
+
+
+class HFAttentionBypass(nn.Module):
+    """Zero-output attention, HF flavour: returns a tuple (reference :416-423)."""
+    def forward(self, hidden_states, head_mask=None, output_attentions: bool = False, *args, **kwargs):
+        z = torch.zeros_like(hidden_states)
+        return (z, None) if output_attentions else (z,)
+
+
+class TimmAttentionBypass(nn.Module):
+    """Zero-output attention, timm flavour (reference :425-429)."""
+    def forward(self, x, *args, **kwargs):
+        return torch.zeros_like(x)
+
+
+def _apply_bypass(vit_model, idx: int) -> None:
+    blocks, kind = _blocks(vit_model)
+    enc = _get_encoder(vit_model)
+    if kind == "hf" and hasattr(blocks[idx], "attention"):
+        enc.layer[idx].attention = HFAttentionBypass()
+    elif kind == "timm" and hasattr(blocks[idx], "attn"):
+        enc.blocks[idx].attn = TimmAttentionBypass()
+
+
+@torch.no_grad()
+def prune_vit_attention_blocks(vit_model, sparsity: float, dataloader=None, device: str = "cuda", batch_limit: int = 5,
+                               metric_fn=None, importance_mode: str = "copy", show_progress: bool = True,
+                               num_to_prune: Optional[int] = None, selected_indices: Optional[List[int]] = None,
+                               *, process_group=None, search: str = "one_shot") -> Dict[str, Any]:
+    """Reference :379-520.  `search="iterative"` adds the greedy K-round variant of the LLM code
+    (src/utilities.py:446-505) with top-1 as the metric."""
+    assert 0.0 <= sparsity < 1.0, "sparsity must be in [0,1)"
+    vit_model.eval()
+    try:
+        num_blocks = len(_blocks(vit_model)[0])
+    except AttributeError:
+        num_blocks = 0
+    if num_to_prune is None:
+        num_to_prune = int(round(num_blocks * sparsity))
+    num_to_prune = max(0, min(num_blocks - 1, int(num_to_prune)))
+    if num_to_prune == 0:
+        return {"model": vit_model, "pruned_indices": [], "original_metrics": None, "final_metrics": None}
+
+    original = final = None
+    if selected_indices is not None:
+        to_prune = sorted(set(i for i in selected_indices if 0 <= i < num_blocks))[:num_to_prune]
+    elif dataloader is None or (isinstance(importance_mode, str) and importance_mode.lower() == "heuristic"):
+        score = [(i if i < num_blocks / 2 else num_blocks - i) for i in range(num_blocks)]
+        to_prune = sorted(range(num_blocks), key=lambda i: score[i])[:num_to_prune]
+    elif search == "iterative":
+        base, _, tot = depth_search_counts(vit_model, dataloader, device, batch_limit, process_group=process_group,
+                                           candidates=[])
+        original = base / max(1, tot)
+        to_prune = []
+        for _ in range(num_to_prune):
+            rest = [i for i in range(num_blocks) if i not in to_prune]
+            _, cc, tot = depth_search_counts(vit_model, dataloader, device, batch_limit, process_group=process_group,
+                                             removed=to_prune, candidates=rest)
+            best = max(rest, key=lambda i: (cc[i], -i))       # highest remaining top-1, ties -> lower index
+            to_prune.append(best)
+    else:
+        base, cc, tot = depth_search_counts(vit_model, dataloader, device, batch_limit, process_group=process_group)
+        original = base / max(1, tot)
+        impact = [max(0.0, original - (c / max(1, tot))) for c in cc]
+        if show_progress:
+            for i, v in enumerate(impact):
+                print(f"[Attn] Block {i} impact: {v:.4f}", flush=True)
+        to_prune = sorted(range(num_blocks), key=lambda i: impact[i])[:num_to_prune]   # stable: ties -> lower index
+
+    for idx in to_prune:
+        _apply_bypass(vit_model, idx)
+    if dataloader is not None:
+        final = evaluate_top1(vit_model, dataloader, device, max_batches=batch_limit, process_group=process_group)
+    return {"model": vit_model, "pruned_indices": sorted(list(to_prune)), "original_metrics": original,
+            "final_metrics": final}
+
+
+# ----------------------------------------------------------------------------- report (reference :877-946)
+def _jsonable(o):
+    try:
+        json.dumps(o)
+        return o
+    except Exception:
+        if isinstance(o, (list, tuple)):
+            return [_jsonable(v) for v in o]
+        if isinstance(o, dict):
+            return {str(k): _jsonable(v) for k, v in o.items()}
+        return str(o)
+
+
+def save_report(report: Dict[str, Any], out_dir: str, run_id: Optional[str] = None) -> Dict[str, str]:
+    """JSON + Markdown report with the reference's file names and section layout."""
+    os.makedirs(out_dir, exist_ok=True)
+    run_id = run_id or time.strftime("%Y%m%d-%H%M%S")
+    jp = os.path.join(out_dir, f"report-{run_id}.json")
+    mp = os.path.join(out_dir, f"report-{run_id}.md")
+    with open(jp, "w", encoding="utf-8") as f:
+        json.dump(_jsonable(report), f, indent=2, ensure_ascii=False)
+    md = [f"# 2SSP ViT Pruning Report ({run_id})", ""]
+    if "config" in report:
+        md += ["## Config"] + [f"- {k}: {v}" for k, v in report["config"].items()] + [""]
+    m = report.get("metrics")
+    if m is not None:
+        g = m.get
+        md += ["## Parameters reduction",
+               f"- Stage-1 (Width): {g('params_before_stage1_millions')}M -> {g('params_after_stage1_millions')}M ({g('stage1_reduction_percent')}%)",
+               f"- Stage-2 (Depth): {g('params_after_stage1_millions')}M -> {g('params_after_stage2_millions')}M ({g('stage2_reduction_percent')}%)",
+               f"- Final result: {g('params_before_stage1_millions')}M -> {g('params_after_stage2_millions')}M ({g('total_reduction_percent')}%)",
+               "", "## Latency", f"- Baseline: {g('latency_baseline_ms')} ms",
+               f"- Stage-1 (Width): {g('latency_stage1_ms')} ms ({g('latency_stage1_change_percent')}%)",
+               f"- Stage-2 (Depth): {g('latency_stage2_ms')} ms ({g('latency_stage2_change_percent')}%)",
+               f"- Final change: {g('latency_total_change_percent')}%", "", "## Accuracy",
+               f"- Baseline: {g('acc_baseline')}",
+               f"- Stage-1 (Width): {g('acc_stage1')} (drop: {g('acc_drop_stage1_percent')}%)",
+               f"- Stage-2 (Depth): {g('acc_stage2')} (drop: {g('acc_drop_stage2_percent')}%)",
+               f"- Final change: {g('acc_total_drop_percent')}%", ""]
+    p = report.get("plan")
+    if p is not None:
+        g = p.get
+        md += ["## Auto-allocation plan", f"- Target sparsity: {g('target_sparsity')}", f"- Blocks total: {g('num_blocks_total')}",
+               f"- Blocks to prune (Stage-2): {g('blocks_to_prune')} ({g('stage2_fraction'):.4f})",
+               f"- Per-block neurons to prune (Stage-1): {g('per_block_neurons_to_prune')}",
+               f"- Estimated total removed params: {g('estimated_total_removed_params')}",
+               f"- Estimation error (params): {g('est_error_params')}", ""]
+    if "artifacts" in report:
+        md += ["## Artifacts"] + [f"- {k}: {v}" for k, v in report["artifacts"].items()] + [""]
+    with open(mp, "w", encoding="utf-8") as f:
+        f.write("\n".join(md))
+    return {"json": jp, "md": mp}

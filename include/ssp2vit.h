@@ -1,0 +1,120 @@
+/*
+ * libssp2vit — C ABI of the MI355X-native 2SSP-for-ViT hot path.
+ *
+ * The reference (zvezdvv/2ssp-X-vit) has NO native boundary: its plug-in surface is Python
+ * (SURVEY.md §8b).  Each entry point below names the reference interface whose device work it
+ * replaces; the Python host layer (2ssp-x-vit_amd/ssp2vit) re-exposes the reference's own function
+ * names on top of these calls, and INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions: every function returns 0 on success, a negative SSP2_E* code otherwise
+ * (ssp2_last_error() gives the message).  All pointers named *_dev are device (HBM) pointers owned by
+ * the caller; nothing here allocates or frees caller memory.  All work is enqueued on the handle's HIP
+ * stream (ssp2_set_stream; default = the NULL stream) and is asynchronous unless stated.  A handle is
+ * thread-compatible, not thread-safe.  No torch types appear anywhere.
+ */
+#ifndef SSP2VIT_H
+#define SSP2VIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSP2_ABI_VERSION 1
+
+enum {
+  SSP2_OK = 0,
+  SSP2_EINVAL = -1,      /* bad argument / shape the kernels do not support   */
+  SSP2_EHIP = -2,        /* a HIP runtime call failed                          */
+  SSP2_ENOMEM = -3,
+  SSP2_ESTATE = -4       /* weights missing, capacity exceeded, ...            */
+};
+
+/* tensor kinds for ssp2_load_tensor (layer index ignored for the model-level ones) */
+enum {
+  SSP2_T_PATCH_W = 0, SSP2_T_PATCH_B, SSP2_T_CLS, SSP2_T_POS,
+  SSP2_T_LN1_G, SSP2_T_LN1_B, SSP2_T_QKV_W, SSP2_T_QKV_B, SSP2_T_PROJ_W, SSP2_T_PROJ_B,
+  SSP2_T_LN2_G, SSP2_T_LN2_B, SSP2_T_FC1_W, SSP2_T_FC1_B, SSP2_T_FC2_W, SSP2_T_FC2_B,
+  SSP2_T_LNF_G, SSP2_T_LNF_B, SSP2_T_HEAD_W, SSP2_T_HEAD_B,
+  SSP2_T_COUNT
+};
+
+/* where the stage-1 score is read (reference hook site, src/vit_pruning.py:130 vs :135) */
+enum { SSP2_SCORE_NONE = 0, SSP2_SCORE_PRE_GELU = 1 /* timm: fc1 out */, SSP2_SCORE_POST_GELU = 2 /* HF: intermediate out */ };
+
+/* score arithmetic: fp32 accumulators end to end, or the reference's CPU-autocast bf16 rounding points
+ * (src/vit_pruning.py:151-157: per-(sample,neuron) norm -> bf16, batch sum -> bf16)                     */
+enum { SSP2_CHAIN_FP32 = 0, SSP2_CHAIN_BF16_REF = 1 };
+
+typedef struct ssp2_engine* ssp2_handle;
+
+typedef struct {
+  int32_t img;          /* input resolution (square)                               */
+  int32_t patch;        /* patch size; tokens N = (img/patch)^2 + 1                */
+  int32_t dim;          /* hidden size, multiple of 64                             */
+  int32_t heads;        /* dim/heads in {16, 64, 80}                               */
+  int32_t depth;        /* encoder blocks L                                        */
+  int32_t classes;
+  float   ln_eps;       /* 1e-6 timm, 1e-12 HF                                     */
+  int32_t max_images;   /* capacity of one forward call (workspace is sized once)  */
+  const int32_t* d_int; /* [depth] FFN width per block (differs after width prune) */
+} ssp2_vit_desc;
+
+int ssp2_abi_version(void);
+const char* ssp2_last_error(void);
+
+/* Replaces: model construction + `.to(device)` of the third-party ViT the reference calls
+ * (src/vit_pruning.py:180, :354).  Allocates bf16 weight storage and the activation workspace. */
+int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out);
+int ssp2_destroy(ssp2_handle h);
+int ssp2_set_stream(ssp2_handle h, void* hip_stream);
+
+/* fp32 HOST data in nn.Linear/Conv2d layout ([out,in], conv [dim,3,p,p]); matrices are rounded to bf16
+ * (RNE) exactly as torch.autocast casts them, biases are rounded to bf16 and kept as fp32 values, LayerNorm
+ * parameters / cls / pos stay fp32.  Synchronous. */
+int ssp2_load_tensor(ssp2_handle h, int kind, int layer, const float* host, size_t numel);
+
+/* a3 (patch-embed conv k=s=p + cls + pos):  pixels_dev f32 NCHW [n,3,img,img]  ->  x_dev f32 [n*N, dim] */
+int ssp2_embed(ssp2_handle h, const float* pixels_dev, int n, float* x_dev);
+
+/* a3/a2/a6: run encoder blocks [l_begin, l_end) in place on the residual stream x_dev [n*N, dim].
+ *   attn_skip      host bytes [depth] or NULL; attn_skip[l]!=0 == the reference's zero-output attention
+ *                  bypass (src/vit_pruning.py:416-429): the block computes x <- x + MLP(LN2(x)) only.
+ *   score_site     SSP2_SCORE_*: if not NONE, row l of batch_scores_dev receives
+ *                  sum_{s<n} || act_l[s,:,j] ||_2 for this call's n samples (the hook body, :151-152),
+ *                  samples added in index order (deterministic, independent of launch geometry).
+ *   batch_scores_dev f32 [depth, score_ld] (rows outside [l_begin,l_end) untouched), score_ld >= max d_int. */
+int ssp2_layers(ssp2_handle h, float* x_dev, int n, int l_begin, int l_end, const uint8_t* attn_skip,
+                int score_site, int score_chain, float* batch_scores_dev, int score_ld);
+
+/* a3 tail + a4: final LayerNorm on the CLS rows, classifier, first-max-index argmax (torch.argmax rule),
+ * comparison with labels.  Any of logits_dev [n,classes] f32, pred_dev [n] i32, labels_dev [n] i64 +
+ * correct_dev [1] i64 (ACCUMULATED into, caller zeroes) may be NULL. */
+int ssp2_head(ssp2_handle h, const float* x_dev, int n, float* logits_dev, int32_t* pred_dev,
+              const int64_t* labels_dev, int64_t* correct_dev);
+
+/* a2 standalone (the hook body on an activation tensor that already sits in HBM):
+ *   act_dev bf16 (dtype 0) or f32 (dtype 1), [n, tokens, ld] with the first d columns used;
+ *   out_dev f32 [d] = sum_s sqrt(sum_t act[s,t,j]^2); norms_ws_dev f32 [n, d] scratch.
+ * HBM-bound: n*tokens*d*sizeof(act) bytes read once. */
+int ssp2_act_l2_accum(void* hip_stream, const void* act_dev, int dtype, int n, int tokens, int d, int ld,
+                      int score_chain, float* norms_ws_dev, float* out_dev);
+
+/* per-kernel-class HIP-event timing (bench.py roofline leg).  klass: see SSP2_K_* */
+enum { SSP2_K_GEMM_FC1 = 0, SSP2_K_GEMM_FC2, SSP2_K_GEMM_QKV, SSP2_K_GEMM_PROJ, SSP2_K_GEMM_PATCH,
+       SSP2_K_GEMM_HEAD, SSP2_K_ATTN, SSP2_K_LN, SSP2_K_SCORE_FINISH, SSP2_K_ACT_L2, SSP2_K_OTHER,
+       SSP2_K_COUNT };
+int ssp2_profile_begin(ssp2_handle h, int klass);                       /* start recording event pairs */
+int ssp2_profile_end(ssp2_handle h, double* total_ms, int64_t* launches); /* synchronises the stream   */
+
+/* workspace / capacity queries */
+int ssp2_tokens(ssp2_handle h);
+size_t ssp2_workspace_bytes(ssp2_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSP2VIT_H */
