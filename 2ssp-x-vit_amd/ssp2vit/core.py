@@ -1,0 +1,160 @@
+"""Engine-level drivers of the two hot loops.  They take a device engine (ssp2vit.engine.VitEngine) — or a
+factory that builds one once the first batch size is known — plus plain metadata, so they serve both the
+reference-named wrappers in `vit_pruning` (live nn.Module in, like the reference) and `bench.py` (flat weights).
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import dist as _dist
+
+
+def iter_limited(dataloader: Iterable, limit: Optional[int], progress: bool, desc: str):
+    it = dataloader
+    if progress:
+        try:
+            from tqdm.auto import tqdm
+            it = tqdm(dataloader, total=limit, desc=desc, leave=False)
+        except Exception:
+            pass
+    for i, batch in enumerate(it):
+        if limit is not None and i >= limit:
+            break
+        yield i, batch
+
+
+def _resolve(engine, min_images: int):
+    return engine(min_images) if callable(engine) else engine
+
+
+@torch.no_grad()
+def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch_limit: Optional[int] = None,
+                  progress: bool = False, score_chain: str = "fp32", process_group=None) -> List[torch.Tensor]:
+    """Reference src/vit_pruning.py:111-201.  `engine`: VitEngine or callable(min_images) -> VitEngine."""
+    rank, ws = _dist.world(process_group)
+    local: List[Tuple[int, torch.Tensor]] = []
+    n_samples = n_batches = 0
+    eng = None
+    for i, batch in iter_limited(dataloader, batch_limit, progress, "S1 activations"):
+        px = batch["pixel_values"]
+        n_samples += int(px.size(0)); n_batches += 1
+        if not _dist.owns(i, rank, ws):
+            continue
+        if eng is None or (callable(engine) and px.size(0) > eng.max_images):
+            eng = _resolve(engine, max(64, int(px.size(0))))
+        local.append((i, eng.forward_scores(px, site, score_chain)))
+
+    vecs = _dist.gather_batch_vectors(local, n_batches, process_group)
+    denom = max(1, n_samples)
+    if not vecs:
+        return [torch.zeros(d) for d in d_ints]
+    if score_chain == "fp32":
+        total = torch.zeros_like(vecs[0])
+        for v in vecs:                          # global batch order: identical on every rank / world size
+            total += v
+        total = (total / denom).to("cpu")
+        return [total[l, :d].clone() for l, d in enumerate(d_ints)]
+    # bf16_ref: the cross-batch `+=` and the final division happen in bf16 exactly as reference :154-157, :200
+    host = [v.to("cpu") for v in vecs]
+    imps: List[torch.Tensor] = []
+    for l, d in enumerate(d_ints):
+        run = None
+        for v in host:
+            acc = v[l, :d].to(torch.bfloat16)   # exact: the kernel already rounded the batch sum to bf16
+            if run is None:
+                run = acc.clone()
+            else:
+                run += acc
+        imps.append(run / denom)
+    return imps
+
+
+@torch.no_grad()
+def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process_group=None,
+                attn_skip: Optional[Sequence[int]] = None) -> Tuple[int, int]:
+    """Reference src/vit_pruning.py:325-373 as integer counts (correct, total)."""
+    rank, ws = _dist.world(process_group)
+    eng = None
+    correct_dev = None
+    total = 0
+    for i, batch in iter_limited(dataloader, max_batches, progress, "eval"):
+        if not _dist.owns(i, rank, ws):
+            continue
+        px, labels = batch["pixel_values"], batch["labels"]
+        if eng is None:
+            eng = _resolve(engine, max(64, int(px.size(0))))
+        if correct_dev is None:
+            correct_dev = torch.zeros(1, dtype=torch.int64, device=eng.device)
+        for s in range(0, px.size(0), eng.max_images):
+            chunk = px[s:s + eng.max_images]
+            x = eng.embed(chunk)
+            eng.layers(x, chunk.size(0), 0, eng.depth, attn_skip)
+            eng.head(x, chunk.size(0), labels=labels[s:s + eng.max_images], correct=correct_dev)
+        total += int(labels.size(0))
+    counts = torch.tensor([0, total], dtype=torch.int64, device=correct_dev.device if correct_dev is not None else "cpu")
+    if correct_dev is not None:
+        counts[0] = correct_dev[0]
+    if ws > 1:
+        counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
+    c = counts.to("cpu")
+    return int(c[0]), int(c[1])
+
+
+@torch.no_grad()
+def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional[int] = 5, process_group=None,
+                        removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None):
+    """One pass over the eval batches that yields the baseline AND every candidate's correct-count.
+
+    The reference deep-copies the model and re-runs the whole forward per candidate (mask_conjunction.py:339-355,
+    src/vit_pruning.py:477-494).  Here the residual stream entering each block is cached during the baseline
+    forward, and candidate i (attention of block i bypassed) restarts from the cached input of block i: blocks
+    0..i-1 are bit-identical to the baseline, so the result equals a full re-run while executing
+    L(L+1)/2 + L block passes per batch instead of L(L+1).
+    Returns (baseline_correct, [candidate_correct per block], total)."""
+    rank, ws = _dist.world(process_group)
+    eng = None
+    L = depth
+    counts_dev = None
+    total = 0
+    removed = sorted(set(int(r) for r in removed))
+    cands = list(range(L)) if candidates is None else [int(c) for c in candidates]
+    for i, batch in iter_limited(dataloader, batch_limit, False, "attn search"):
+        if not _dist.owns(i, rank, ws):
+            continue
+        px_all, labels_all = batch["pixel_values"], batch["labels"]
+        if eng is None:
+            eng = _resolve(engine, max(64, int(px_all.size(0))))
+        if counts_dev is None:
+            counts_dev = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
+        for s in range(0, px_all.size(0), eng.max_images):
+            px = px_all[s:s + eng.max_images]
+            labels = labels_all[s:s + eng.max_images].to(eng.device)
+            n = px.size(0)
+            x = eng.embed(px)
+            cache = {}
+            for l in range(L):
+                if l in cands:
+                    cache[l] = x.clone()
+                eng.layers(x, n, l, l + 1, removed)
+            eng.head(x, n, labels=labels, correct=counts_dev[L:L + 1])
+            for c in cands:
+                xc = cache.pop(c)
+                eng.layers(xc, n, c, L, removed + [c])
+                eng.head(xc, n, labels=labels, correct=counts_dev[c:c + 1])
+        total += int(labels_all.size(0))
+    if counts_dev is None:
+        counts = torch.zeros(L + 2, dtype=torch.int64)
+    else:
+        counts = torch.cat([counts_dev, torch.tensor([total], dtype=torch.int64, device=counts_dev.device)])
+    if ws > 1:
+        counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
+    c = counts.to("cpu").tolist()
+    return c[-2], c[:-2], c[-1]
+
+
+def impacts_from_counts(base: int, cand: Sequence[int], total: int) -> List[float]:
+    """impact_i = max(0, baseline - acc_i) with the reference's float arithmetic (mask_conjunction.py:329-348)."""
+    baseline = float(base / max(1, total))
+    return [max(0.0, baseline - float(c / max(1, total))) for c in cand]

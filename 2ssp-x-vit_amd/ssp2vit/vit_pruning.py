@@ -19,6 +19,7 @@ from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 import torch
 import torch.nn as nn
 
+from . import core as _core
 from . import dist as _dist
 from . import weights as _weights
 from .planner import ModelStats, TwoSSPPlan, plan_from_stats
@@ -129,18 +130,10 @@ def release_engines() -> None:
     _ENGINES.clear()
 
 
-def _iter_limited(dataloader: Iterable, limit: Optional[int], progress: bool, desc: str):
-    it = dataloader
-    if progress:
-        try:
-            from tqdm.auto import tqdm
-            it = tqdm(dataloader, total=limit, desc=desc, leave=False)
-        except Exception:
-            pass
-    for i, batch in enumerate(it):
-        if limit is not None and i >= limit:
-            break
-        yield i, batch
+def _engine_factory(model, device, engine):
+    if engine is not None:
+        return engine
+    return lambda n: engine_for(model, device, max_images=n)
 
 
 # ----------------------------------------------------------------------------- a1/a2 stage-1 scores
@@ -154,47 +147,12 @@ def _compute_ffn_activation_importance(vit_model, dataloader, device: str = "cud
     Returns List[L] of CPU tensors [d_int]: float32 with score_chain="fp32" (default; fp32 accumulators end to
     end), bfloat16 with score_chain="bf16_ref" (the reference's CPU-autocast rounding points)."""
     vit_model.eval()
-    blocks, kind = _blocks(vit_model)           # raises AttributeError on unknown anatomy like the reference
+    _, kind = _blocks(vit_model)                # raises AttributeError on unknown anatomy like the reference
     d_ints = [p[0].out_features for p in _gather_mlp_pairs(vit_model)]
     site = _weights.score_site_for("timm" if kind == "timm" else "hf")
-    rank, ws = _dist.world(process_group)
-
-    local: List[Tuple[int, torch.Tensor]] = []
-    seen = torch.zeros(2, dtype=torch.int64)    # [samples over ALL batches, number of batches]
-    eng = engine
-    for i, batch in _iter_limited(dataloader, batch_limit, progress, "S1 activations"):
-        px = batch["pixel_values"]
-        seen[0] += int(px.size(0)); seen[1] += 1
-        if not _dist.owns(i, rank, ws):
-            continue
-        if eng is None or (engine is None and px.size(0) > eng.max_images):
-            eng = engine_for(vit_model, device, max_images=max(64, int(px.size(0))))
-        local.append((i, eng.forward_scores(px, site, score_chain)))
-
-    n_batches, n_samples = int(seen[1]), int(seen[0])
-    vecs = _dist.gather_batch_vectors(local, n_batches, process_group)
-    denom = max(1, n_samples)
-    imps: List[torch.Tensor] = []
-    if not vecs:
-        return [torch.zeros(d) for d in d_ints]
-    if score_chain == "fp32":
-        total = torch.zeros_like(vecs[0])
-        for v in vecs:                          # global batch order: identical on every rank / world size
-            total += v
-        total = (total / denom).to("cpu")
-        return [total[l, :d].clone() for l, d in enumerate(d_ints)]
-    # bf16_ref: the cross-batch `+=` and the final division happen in bf16 exactly as reference :154-157, :200
-    host = [v.to("cpu") for v in vecs]
-    for l, d in enumerate(d_ints):
-        run = None
-        for v in host:
-            acc = v[l, :d].to(torch.bfloat16)   # exact: the kernel already rounded the batch sum to bf16
-            if run is None:
-                run = acc.clone()
-            else:
-                run += acc
-        imps.append(run / denom)
-    return imps
+    return _core.stage1_scores(_engine_factory(vit_model, device, engine), dataloader, d_ints, site,
+                               batch_limit=batch_limit, progress=progress, score_chain=score_chain,
+                               process_group=process_group)
 
 
 # ----------------------------------------------------------------------------- a7/a8 width prune (host consumer)
@@ -268,31 +226,8 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
 @torch.no_grad()
 def _top1_counts(model, dataloader, device="cuda", max_batches=None, progress=False, *, process_group=None,
                  engine=None, attn_skip: Optional[Sequence[int]] = None) -> Tuple[int, int]:
-    rank, ws = _dist.world(process_group)
-    eng = engine
-    correct_dev = None
-    total = 0
-    for i, batch in _iter_limited(dataloader, max_batches, progress, "eval"):
-        if not _dist.owns(i, rank, ws):
-            continue
-        px, labels = batch["pixel_values"], batch["labels"]
-        if eng is None:
-            eng = engine_for(model, device, max_images=max(64, int(px.size(0))))
-        if correct_dev is None:
-            correct_dev = torch.zeros(1, dtype=torch.int64, device=eng.device)
-        for s in range(0, px.size(0), eng.max_images):
-            chunk = px[s:s + eng.max_images]
-            x = eng.embed(chunk)
-            eng.layers(x, chunk.size(0), 0, eng.depth, attn_skip)
-            eng.head(x, chunk.size(0), labels=labels[s:s + eng.max_images], correct=correct_dev)
-        total += int(labels.size(0))
-    counts = torch.tensor([0, total], dtype=torch.int64, device=correct_dev.device if correct_dev is not None else "cpu")
-    if correct_dev is not None:
-        counts[0] = correct_dev[0]
-    if ws > 1:
-        counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
-    c = counts.to("cpu")
-    return int(c[0]), int(c[1])
+    return _core.top1_counts(_engine_factory(model, device, engine), dataloader, max_batches=max_batches,
+                             progress=progress, process_group=process_group, attn_skip=attn_skip)
 
 
 @torch.no_grad()
@@ -308,56 +243,10 @@ def evaluate_top1(model, dataloader, device: str = "cuda", max_batches: int | No
 @torch.no_grad()
 def depth_search_counts(model, dataloader, device="cuda", batch_limit: Optional[int] = 5, *, process_group=None,
                         engine=None, removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None):
-    """One pass over the eval batches that yields the baseline AND every candidate's correct-count.
-
-    The reference deep-copies the model and re-runs the whole forward per candidate (mask_conjunction.py:339-355,
-    src/vit_pruning.py:477-494).  Here the residual stream entering each block is cached during the baseline
-    forward, and candidate i (attention of block i bypassed) restarts from the cached input of block i: blocks
-    0..i-1 are bit-identical to the baseline, so the result equals a full re-run while executing
-    L(L+1)/2 + L block passes per batch instead of L(L+1).
-    Returns (baseline_correct, [candidate_correct], total)."""
-    rank, ws = _dist.world(process_group)
-    eng = engine
-    L = None
-    counts_dev = None
-    total = 0
-    removed = sorted(set(int(r) for r in removed))
-    for i, batch in _iter_limited(dataloader, batch_limit, False, "attn search"):
-        if not _dist.owns(i, rank, ws):
-            continue
-        px_all, labels_all = batch["pixel_values"], batch["labels"]
-        if eng is None:
-            eng = engine_for(model, device, max_images=max(64, int(px_all.size(0))))
-        L = eng.depth
-        cands = list(range(L)) if candidates is None else [int(c) for c in candidates]
-        if counts_dev is None:
-            counts_dev = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
-        for s in range(0, px_all.size(0), eng.max_images):
-            px = px_all[s:s + eng.max_images]
-            labels = labels_all[s:s + eng.max_images].to(eng.device)
-            n = px.size(0)
-            x = eng.embed(px)
-            cache = {}
-            first = min(cands) if cands else L
-            for l in range(L):
-                if l >= first and l in cands:
-                    cache[l] = x.clone()
-                eng.layers(x, n, l, l + 1, removed)
-            eng.head(x, n, labels=labels, correct=counts_dev[L:L + 1])
-            for c in cands:
-                xc = cache.pop(c)
-                eng.layers(xc, n, c, L, removed + [c])
-                eng.head(xc, n, labels=labels, correct=counts_dev[c:c + 1])
-        total += int(labels_all.size(0))
-    if counts_dev is None:
-        L = len(_blocks(model)[0]) if L is None else L
-        counts = torch.zeros(L + 2, dtype=torch.int64)
-    else:
-        counts = torch.cat([counts_dev, torch.tensor([total], dtype=torch.int64, device=counts_dev.device)])
-    if ws > 1:
-        counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
-    c = counts.to("cpu").tolist()
-    return c[-2], c[:-2], c[-1]
+    """(baseline_correct, [candidate_correct], total) — see core.depth_search_counts (prefix-cached search)."""
+    return _core.depth_search_counts(_engine_factory(model, device, engine), dataloader, len(_blocks(model)[0]),
+                                     batch_limit=batch_limit, process_group=process_group, removed=removed,
+                                     candidates=candidates)
 
 
 class HFAttentionBypass(nn.Module):

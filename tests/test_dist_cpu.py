@@ -1,0 +1,129 @@
+"""N>1 path on CPU: two gloo ranks shard the calibration / eval batches exactly as the RCCL path does on GPUs
+(batch i -> rank i % P, one all_gather of per-batch score vectors, one all_reduce of int64 correct-counts).
+The device engine is replaced by an oracle-backed stand-in (TEST infrastructure only; the product never
+constructs it), so what is tested is the host sharding/ordering logic: results must be bit-identical to ws=1."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT, load_tiny_golden
+
+
+class OracleBackedEngine:
+    """Duck-types ssp2vit.engine.VitEngine on CPU through the oracle's TimmLayoutViT."""
+
+    def __init__(self, model, max_images=64):
+        self.m = model.eval()
+        self.depth = len(model.blocks)
+        self.device = torch.device("cpu")
+        self.max_images = max_images
+        self.tokens = model.pos_embed.shape[1]
+        self.dim = model.pos_embed.shape[2]
+
+    @torch.no_grad()
+    def embed(self, px):
+        with torch.autocast("cpu", enabled=True):
+            t = self.m.patch_embed(px)
+            t = torch.cat((self.m.cls_token.expand(t.shape[0], -1, -1), t), 1) + self.m.pos_embed
+        return t.float().reshape(-1, self.dim).contiguous()
+
+    @torch.no_grad()
+    def layers(self, x, n, l_begin=0, l_end=None, attn_skip=None, score_site="none", score_chain="fp32", batch_scores=None):
+        l_end = self.depth if l_end is None else l_end
+        skip = set(int(i) for i in (attn_skip or []))
+        t = x.view(n, self.tokens, self.dim)
+        with torch.autocast("cpu", enabled=True):
+            for l in range(l_begin, l_end):
+                b = self.m.blocks[l]
+                if l not in skip:
+                    t = t + b.attn(b.norm1(t))
+                t = t + b.mlp(b.norm2(t))
+        x.copy_(t.float().reshape(-1, self.dim))
+
+    @torch.no_grad()
+    def head(self, x, n, labels=None, correct=None, want_logits=False, want_pred=False):
+        with torch.autocast("cpu", enabled=True):
+            lg = self.m.head(self.m.norm(x.view(n, self.tokens, self.dim))[:, 0])
+        if labels is not None:
+            correct += (lg.argmax(-1) == labels).sum()
+        return lg, lg.argmax(-1), correct
+
+    @torch.no_grad()
+    def forward_scores(self, px, site, chain):
+        from oracle import ref_cpu
+        imps = ref_cpu.ffn_activation_importance(self.m, [{"pixel_values": px}], chain="fp32")
+        return torch.stack([t * px.shape[0] for t in imps])     # un-normalised per-batch sums [L, d_int]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batches():
+    w, _, _ = load_tiny_golden("timm")
+    g = torch.Generator().manual_seed(11)
+    out = []
+    for i in range(5):                                          # 5 batches over 2 ranks: ragged ownership (3 + 2)
+        n = 4 if i < 4 else 3                                   # ragged last batch
+        px = torch.randn(n, 3, 32, 32, generator=g)
+        out.append({"pixel_values": px, "labels": torch.randint(0, 10, (n,), generator=g)})
+    return w, out
+
+
+def _run_all(process_group=None):
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    w, batches = _batches()
+    model = build_from_flat(w, "timm")
+    eng = OracleBackedEngine(model)
+    imps = vp._compute_ffn_activation_importance(model, batches, device="cpu", engine=eng, process_group=process_group)
+    imps3 = vp._compute_ffn_activation_importance(model, batches, device="cpu", batch_limit=3, engine=eng,
+                                                  process_group=process_group)
+    counts = vp.depth_search_counts(model, batches, "cpu", None, engine=eng, process_group=process_group)
+    top1 = vp._top1_counts(model, batches, "cpu", None, engine=eng, process_group=process_group)
+    return imps, imps3, counts, top1
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        res = _run_all()
+        torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_results_equal_single_process(tmp_path):
+    torch.set_num_threads(2)
+    ref = _run_all()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        imps, imps3, counts, top1 = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        for a, b in zip(imps, ref[0]):
+            assert torch.equal(a, b)                            # bitwise: global batch order, not arrival order
+        for a, b in zip(imps3, ref[1]):
+            assert torch.equal(a, b)
+        assert counts == ref[2] and top1 == ref[3]
+    assert ref[2][2] == 19 and ref[3][1] == 19                  # every image counted exactly once
+
+
+def test_gather_is_identity_without_process_group():
+    from ssp2vit import dist as D
+    v = [(2, torch.ones(1, 2) * 2), (0, torch.zeros(1, 2)), (1, torch.ones(1, 2))]
+    out = D.gather_batch_vectors(v, 3)
+    assert [float(t[0, 0]) for t in out] == [0.0, 1.0, 2.0]
+    assert D.world() == (0, 1) and D.owns(3, 0, 1)

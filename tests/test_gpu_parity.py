@@ -1,0 +1,278 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI, against the CPU oracle
+and the committed golden fixtures.  /root/reference is never read here.
+
+Tolerances (stated once, used below).  The oracle runs PyTorch CPU bf16-autocast; the engine runs bf16 MFMA with
+fp32 accumulators and rounds at the same points, so differences come only from fp32 summation order and the
+occasional 1-ulp bf16 flip it causes downstream:
+  * integer / index results (argmax rule, correct counts given logits, masks given scores, prefix-cache search vs
+    full re-run, run-to-run and fused-vs-unfused determinism): BIT-EXACT
+  * standalone activation-L2 kernel vs float64: rel 2e-6
+  * stage-1 scores, fp32 chain: rel 2e-3 (+1e-4 abs); bf16_ref chain: <= 1 bf16 ulp per element per batch (<= 2 over
+    two accumulated batches), >= 90 % of elements exact
+  * logits: |err| <= 2 bf16 ulp of the largest logit magnitude (2 * 2^-8 * max|logit|)
+  * top-1 correct counts vs oracle: within 1 image per 16 on synthetic weights (small logit margins)
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, bf16_from_bits, load_tiny_golden
+
+pytestmark = pytest.mark.gpu
+
+SITE = {"timm": "pre_gelu", "hf": "post_gelu"}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    return torch.device("cuda:0")
+
+
+def _engine(w, n):
+    from ssp2vit.engine import VitEngine
+    return VitEngine(w, device="cuda:0", max_images=n)
+
+
+def _logit_tol(ref):
+    return 2.0 * 2.0 ** -8 * float(ref.abs().max())
+
+
+# ------------------------------------------------------------------------------------------ plumbing
+def test_library_is_the_in_tree_hip_build(gpu):
+    from ssp2vit import _lib
+    lib = _lib.load(build_if_missing=False)
+    assert lib.ssp2_abi_version() == 1
+    assert os.path.realpath(lib._name).startswith(os.path.realpath(_lib.PKG_ROOT))
+
+
+# ------------------------------------------------------------------------------------------ a2 standalone kernel
+@pytest.mark.parametrize("shape", [(5, 197, 3072), (3, 5, 128), (2, 1, 64), (1, 257, 5120), (7, 50, 200)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_act_l2_accum_vs_float64(gpu, shape, dtype):
+    from oracle import ref_cpu
+    w, _, _ = load_tiny_golden("timm")
+    eng = _engine(w, 4)
+    g = torch.Generator().manual_seed(7)
+    act = (torch.randn(*shape, generator=g) * 3).to(dtype).to(gpu)
+    out = eng.act_l2_accum(act).cpu().double().numpy()
+    ref = ref_cpu.act_l2_accum_f64(act.float().cpu().numpy())
+    assert np.allclose(out, ref, rtol=2e-6, atol=0)
+
+
+def test_act_l2_accum_edge_values(gpu):
+    w, _, _ = load_tiny_golden("timm")
+    eng = _engine(w, 4)
+    act = torch.zeros(2, 9, 64, dtype=torch.bfloat16, device=gpu)
+    assert torch.equal(eng.act_l2_accum(act).cpu(), torch.zeros(64))          # all-zero neurons score exactly 0
+    act[1, 3, 5] = 3.0; act[1, 4, 5] = 4.0
+    out = eng.act_l2_accum(act).cpu()
+    assert out[5] == 5.0 and out.sum() == 5.0                                  # sqrt(9+16), one sample
+    with pytest.raises(ValueError):
+        eng.act_l2_accum(act.transpose(1, 2))                                  # non-contiguous is refused
+    from ssp2vit._lib import Ssp2Error
+    with pytest.raises(Ssp2Error):
+        eng.act_l2_accum(torch.zeros(2, 3, 12, dtype=torch.bfloat16, device=gpu))  # d % 8 != 0
+
+
+def test_act_l2_bf16_ref_chain_matches_torch_chain(gpu):
+    """chain=bf16_ref: per-(sample,neuron) norm rounded to bf16, batch sum rounded to bf16 (reference :151-152)."""
+    w, _, _ = load_tiny_golden("timm")
+    eng = _engine(w, 4)
+    g = torch.Generator().manual_seed(3)
+    act = torch.randn(8, 197, 768, generator=g).to(torch.bfloat16)
+    ref = torch.linalg.vector_norm(act, ord=2, dim=1).sum(dim=0)               # bf16 chain on CPU
+    out = eng.act_l2_accum(act.to(gpu), "bf16_ref").cpu().to(torch.bfloat16)
+    ulp = (out.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+    assert int(ulp.max()) <= 1 and float((ulp == 0).float().mean()) >= 0.9
+
+
+# ------------------------------------------------------------------------------------------ forward vs oracle
+@pytest.mark.parametrize("layout", ["timm", "hf"])
+def test_tiny_logits_scores_and_skip_vs_oracle(gpu, layout):
+    from oracle import ref_cpu
+    from oracle.vit_modules import build_from_flat
+    w, batches, z = load_tiny_golden(layout)
+    model = build_from_flat(w, layout)
+    eng = _engine(w, 16)
+    for b in batches:
+        px = b["pixel_values"]
+        ref = ref_cpu.logits_of(model, px).float()
+        got = eng.forward_logits(px.to(gpu)).cpu()
+        assert (got - ref).abs().max() <= _logit_tol(ref)
+        for i in range(4):                                                       # a6: attention bypass semantics
+            m2 = copy.deepcopy(model)
+            ref_cpu.bypass_attention_(m2, i)
+            r2 = ref_cpu.logits_of(m2, px).float()
+            g2 = eng.forward_logits(px.to(gpu), attn_skip=[i]).cpu()
+            assert (g2 - r2).abs().max() <= _logit_tol(r2)
+    # stage-1 scores, both chains (5 tokens < 128: the UNFUSED path, standalone L2 kernel on the stored activation)
+    px = batches[0]["pixel_values"]
+    ref32 = ref_cpu.ffn_activation_importance(model, [batches[0]], chain="fp32")
+    got = eng.forward_scores(px.to(gpu), SITE[layout], "fp32").cpu() / px.shape[0]
+    for l in range(4):
+        assert torch.allclose(got[l, :128], ref32[l], rtol=2e-3, atol=1e-4)
+    refb = [bf16_from_bits(z[f"s1_imp_limit1_bf16bits.{l}"]) for l in range(4)]     # REAL reference output
+    gotb = eng.forward_scores(px.to(gpu), SITE[layout], "bf16_ref").cpu()
+    for l in range(4):
+        a = gotb[l, :128].to(torch.bfloat16) / px.shape[0]
+        ulp = (a.view(torch.int16).int() - refb[l].view(torch.int16).int()).abs()
+        assert int(ulp.max()) <= 1 and float((ulp == 0).float().mean()) >= 0.9
+
+
+def test_vit_tiny16_config0_fused_scores_vs_golden_and_oracle(gpu):
+    """BASELINE.json configs[0] shapes on the GPU: ViT-Tiny/16, 32 calibration images (2 x 16), 197 tokens =>
+    the FUSED fc1+GELU+L2 epilogue path.  bf16_ref chain is compared with the golden captured from the reference."""
+    from oracle import ref_cpu
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit.weights import synthetic_weights
+    from ssp2vit import vit_pruning as vp
+    z = dict(np.load(os.path.join(GOLDEN, "vit_tiny16_stage1.npz")))
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=0, std=0.02, eps=1e-6)
+    model = build_from_flat(w, "timm")
+    g = torch.Generator().manual_seed(1)
+    batches = [{"pixel_values": torch.randn(16, 3, 224, 224, generator=g)} for _ in range(2)]
+    imps = vp._compute_ffn_activation_importance(model, batches, device="cuda", score_chain="bf16_ref")
+    for l, t in enumerate(imps):
+        assert t.dtype == torch.bfloat16 and t.shape == (768,)
+        ref = bf16_from_bits(z[f"s1_imp_bf16bits.{l}"])
+        ulp = (t.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+        assert int(ulp.max()) <= 2 and float((ulp == 0).float().mean()) >= 0.9, (l, int(ulp.max()))   # 2 batches: two bf16 roundings can stack
+    imps32 = vp._compute_ffn_activation_importance(model, batches, device="cuda")            # default fp32 chain
+    ref32 = ref_cpu.ffn_activation_importance(model, batches, chain="fp32")
+    for a, b in zip(imps32, ref32):
+        assert a.dtype == torch.float32 and torch.allclose(a, b, rtol=2e-3, atol=1e-4)
+    # run-to-run determinism is bitwise
+    again = vp._compute_ffn_activation_importance(model, batches, device="cuda")
+    assert all(torch.equal(a, b) for a, b in zip(imps32, again))
+    # post-GELU site (HF anatomy) through the same fused epilogue
+    mh = build_from_flat(w, "hf")
+    imps_h = vp._compute_ffn_activation_importance(mh, batches[:1], device="cuda")
+    ref_h = ref_cpu.ffn_activation_importance(mh, batches[:1], chain="fp32")
+    for a, b in zip(imps_h, ref_h):
+        assert torch.allclose(a, b, rtol=2e-3, atol=1e-4)
+    vp.release_engines()
+
+
+def test_fused_epilogue_equals_unfused_kernel_bitwise_inputs(gpu):
+    """Same activations, two code paths: the fc1 epilogue's fused partial sums and the standalone HBM kernel.
+    Ragged case: 3 images x 197 tokens (tiles straddle samples, last tile partly empty)."""
+    from ssp2vit.weights import synthetic_weights
+    from ssp2vit.engine import VitEngine
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=2, std=0.05, eps=1e-6, bias_std=0.02)
+    eng = VitEngine(w, max_images=3)
+    g = torch.Generator().manual_seed(5)
+    px = torch.randn(3, 3, 224, 224, generator=g).to(gpu)
+    fused = eng.forward_scores(px, "post_gelu", "fp32")
+    # per-image calls exercise n=1 (a single sample, tiles never straddle) and must add up to the batch result
+    parts = [eng.forward_scores(px[i:i + 1], "post_gelu", "fp32") for i in range(3)]
+    seq = parts[0].clone()
+    for p in parts[1:]:
+        seq += p
+    assert torch.allclose(fused, seq, rtol=1e-6, atol=0)
+
+
+# ------------------------------------------------------------------------------------------ a4 top-1 (integer part)
+def test_argmax_first_max_index_rule_and_counts(gpu):
+    w, batches, _ = load_tiny_golden("timm")
+    w = dict(w)
+    hw = w["head_w"].clone(); hb = w["head_b"].clone()
+    hw[7] = hw[2]; hb[7] = hb[2]; hw[9] = hw[2]; hb[9] = hb[2]          # classes 2, 7, 9 always tie exactly
+    w["head_w"], w["head_b"] = hw, hb
+    eng = _engine(w, 16)
+    px = torch.cat([b["pixel_values"] for b in batches])
+    labels = torch.cat([b["labels"] for b in batches])
+    x = eng.embed(px.to(gpu))
+    eng.layers(x, 16)
+    logits, pred, correct = eng.head(x, 16, labels=labels.to(gpu), want_logits=True, want_pred=True)
+    lg = logits.cpu()
+    assert torch.equal(lg[:, 2], lg[:, 7]) and torch.equal(lg[:, 2], lg[:, 9])
+    assert torch.equal(pred.cpu().long(), lg.argmax(-1))                  # torch rule: lowest index among equal maxima
+    assert not ((pred.cpu() == 7) | (pred.cpu() == 9)).any()
+    assert int(correct.item()) == int((lg.argmax(-1) == labels).sum())
+
+
+@pytest.mark.parametrize("layout", ["timm", "hf"])
+def test_evaluate_top1_and_depth_importance_vs_golden(gpu, layout):
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    from ssp2vit.mask_conjunction import Auto2SSPInterface
+    w, batches, z = load_tiny_golden(layout)
+    model = build_from_flat(w, layout)
+    acc = vp.evaluate_top1(model, batches, device="cuda")
+    assert abs(acc - float(z["top1"])) <= 1 / 16 + 1e-9
+    assert abs(vp.evaluate_top1(model, batches, device="cuda", max_batches=1) - float(z["top1_limit1"])) <= 1 / 8 + 1e-9
+    iface = Auto2SSPInterface(model, batches, device="cuda", importance_mode="copy", batch_limit=5)
+    att, mlp = iface.fit()
+    assert att.dtype == torch.float32 and att.shape == (4,) and (att >= 0).all()
+    assert np.abs(att.numpy() - z["att_imp"]).max() <= 2 / 16 + 1e-6          # each accuracy within 1 image of 16
+    assert len(mlp) == 4 and all(t.dim() == 1 and t.numel() == 128 and t.device.type == "cpu" for t in mlp)
+    vp.release_engines()
+
+
+def test_depth_search_prefix_cache_equals_full_rerun_exactly(gpu):
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    w, batches, _ = load_tiny_golden("timm")
+    model = build_from_flat(w, "timm")
+    base, cand, total = vp.depth_search_counts(model, batches, "cuda", 5)
+    assert total == 16
+    assert (base, total) == vp._top1_counts(model, batches, "cuda", 5)
+    for i in range(4):
+        assert (cand[i], total) == vp._top1_counts(model, batches, "cuda", 5, attn_skip=[i])
+    # skip == zeroed out-projection (x += bf16(0 + 0) is exact): two different code paths, same integers
+    m2 = copy.deepcopy(model)
+    with torch.no_grad():
+        m2.blocks[1].attn.proj.weight.zero_(); m2.blocks[1].attn.proj.bias.zero_()
+    assert vp._top1_counts(m2, batches, "cuda", 5)[0] == cand[1]
+    vp.release_engines()
+
+
+# ------------------------------------------------------------------------------------------ reference's own tests, mirrored
+def test_stage2_attention_only_like_reference_smoke(gpu):
+    """Mirrors experiments/vit_pruning/test_stage2_attention_only.py:40-106 (tiny HF config, heuristic, K=2)."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    w, batches, z = load_tiny_golden("hf")
+    model = build_from_flat(w, "hf")
+    mlp_before = [sum(p.numel() for p in l.intermediate.parameters()) + sum(p.numel() for p in l.output.parameters())
+                  for l in model.vit.encoder.layer]
+    res = vp.prune_vit_attention_blocks(model, sparsity=0.5, dataloader=None, device="cuda", importance_mode="heuristic",
+                                        show_progress=False, num_to_prune=2)
+    assert res["pruned_indices"] == z["s2_heur.pruned"].tolist()
+    assert len(model.vit.encoder.layer) == 4
+    for i, l in enumerate(model.vit.encoder.layer):
+        n_attn = sum(p.numel() for p in l.attention.parameters())
+        assert (n_attn == 0) == (i in res["pruned_indices"])
+    assert mlp_before == [sum(p.numel() for p in l.intermediate.parameters()) + sum(p.numel() for p in l.output.parameters())
+                          for l in model.vit.encoder.layer]
+    eng = vp.engine_for(model, "cuda", 16)                     # engine built from the module WITH bypasses
+    lg = eng.forward_logits(batches[0]["pixel_values"].to(gpu))
+    assert lg.shape == (8, 10) and torch.isfinite(lg).all()
+    vp.release_engines()
+
+
+def test_copy_mode_selection_and_width_prune_end_to_end(gpu):
+    from oracle import ref_cpu
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    w, batches, z = load_tiny_golden("timm")
+    model = build_from_flat(w, "timm")
+    imps = vp._compute_ffn_activation_importance(model, batches, device="cuda")
+    res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[40] * 4, min_remaining=16, collect_masks=True,
+                                 precomputed_importance=imps)
+    assert all(sum(m) == 40 for m in res["ffn_prune_masks"])
+    assert [b.mlp.fc1.out_features for b in model.blocks] == [88] * 4
+    # the pruned module (d_int 88 -> padded to 128 inside the engine) still matches the oracle run on it
+    px = batches[0]["pixel_values"]
+    ref = ref_cpu.logits_of(model, px).float()
+    got = vp.engine_for(model, "cuda", 16).forward_logits(px.to(gpu)).cpu()
+    assert (got - ref).abs().max() <= _logit_tol(ref)
+    out = vp.prune_vit_attention_blocks(model, sparsity=0.5, dataloader=batches, device="cuda", batch_limit=5,
+                                        importance_mode="copy", show_progress=False, num_to_prune=2)
+    assert len(out["pruned_indices"]) == 2 and out["original_metrics"] is not None and out["final_metrics"] is not None
+    vp.release_engines()

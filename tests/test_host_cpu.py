@@ -1,0 +1,196 @@
+"""CPU-side tests (`-m "not gpu"`): host logic, the planner against reference known-answers, the C-ABI library's
+exported symbols, loud failure without a GPU, and the world_size-2 sharding path over gloo."""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, PKG, ROOT, bf16_from_bits, load_tiny_golden
+
+
+# ------------------------------------------------------------------------------------------ planner (f3)
+def test_planner_known_answers_from_reference():
+    from ssp2vit.planner import plan_from_stats, stats_from_shapes
+    from ssp2vit.weights import VIT_CONFIGS
+    gold = json.load(open(os.path.join(GOLDEN, "planner.json")))
+    assert len(gold) >= 20
+    for g in gold:
+        img, patch, dim, heads, inter, depth = VIT_CONFIGS[g["model"]]
+        st = stats_from_shapes(dim, depth, inter, g["classes"], (img // patch) ** 2 + 1, patch)
+        assert st.total_params == g["total_params"]
+        plan = plan_from_stats(st, g["target"], g["min_remaining"], g["forced_blocks"])
+        assert plan.__dict__ == g["plan"], (g["model"], g["target"])
+    # headline config: ViT-B/16 @ 37.5 %  ->  K=5 attention blocks, t=1120 neurons per block
+    st = stats_from_shapes(768, 12, 3072, 1000, 197, 16)
+    p = plan_from_stats(st, 0.375, 512)
+    assert (p.blocks_to_prune, p.per_block_neurons_to_prune, p.est_error_params) == (5, 1120, 6249)
+
+
+def test_planner_on_live_module_and_errors():
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    w, _, _ = load_tiny_golden("hf")
+    for layout in ("hf", "timm"):
+        m = build_from_flat(w, layout)
+        plan = vp.plan_2ssp_allocation(m, 0.3, min_remaining=16)
+        assert (plan.blocks_to_prune, plan.per_block_neurons_to_prune, plan.est_error_params) == (3, 10, 200)
+        assert vp.count_total_params(m) == sum(p.numel() for p in m.parameters())
+        assert len(vp.count_block_params(m)) == 4
+    with pytest.raises(AssertionError):
+        vp.plan_2ssp_allocation(m, 1.0)
+    with pytest.raises(AttributeError):
+        vp.count_block_params(torch.nn.Linear(2, 2))
+    assert vp.compute_actual_sparsity(0, 5) == 0.0 and vp.compute_actual_sparsity(100, 75) == 0.25
+
+
+# ------------------------------------------------------------------------------------------ mask step (a7/a8)
+@pytest.mark.parametrize("layout", ["timm", "hf"])
+def test_width_prune_mask_step_matches_reference_golden(layout):
+    from oracle import ref_cpu
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    w, batches, z = load_tiny_golden(layout)
+    imps = [bf16_from_bits(z[f"s1_imp_bf16bits.{i}"]).to(torch.float32) for i in range(4)]
+    model = build_from_flat(w, layout)
+    res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[40] * 4, min_remaining=16, collect_masks=True,
+                                 precomputed_importance=imps)
+    assert np.array_equal(np.asarray(res["ffn_prune_masks"], dtype=np.int16), z["mask.t40"])
+    assert np.array_equal(np.asarray(res["ffn_pruned_indices"]), z["pruned_idx.t40"])
+    assert res["model"] is model
+    # weight surgery equals the reference's: the pruned model's top-1 (oracle forward) equals the stored value
+    assert ref_cpu.evaluate_top1(model, batches) == float(z["top1_after.t40"])
+    pairs = vp._gather_mlp_pairs(model)
+    assert all(a.out_features == 88 and a.weight.shape == (88, 64) and b.weight.shape == (64, 88) for a, b in pairs)
+    # clamp by min_remaining
+    model = build_from_flat(w, layout)
+    res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[100] * 4, min_remaining=64, collect_masks=True,
+                                 precomputed_importance=imps)
+    assert np.array_equal(np.asarray(res["ffn_prune_masks"], dtype=np.int16), z["mask.t100_clamped"])
+
+
+def test_width_prune_argument_errors_like_reference():
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    w, _, _ = load_tiny_golden("timm")
+    m = build_from_flat(w, "timm")
+    with pytest.raises(ValueError):
+        vp.prune_vit_mlp_width(m, n_to_prune_per_block=[1, 2])
+    with pytest.raises(ValueError):
+        vp.prune_vit_mlp_width(m)
+    with pytest.raises(AssertionError):
+        vp.prune_vit_mlp_width(m, sparsity=1.0)
+    with pytest.raises(ValueError):
+        vp.prune_vit_mlp_width(m, sparsity=0.1, precomputed_importance=[torch.zeros(128)])
+    with pytest.raises(RuntimeError):
+        vp.prune_vit_mlp_width(m, sparsity=0.1, precomputed_importance=[torch.zeros(5)] * 4)
+    with pytest.raises(ValueError):
+        vp.prune_vit_mlp_width(m, sparsity=0.1, strategy="nope")
+    with pytest.raises(RuntimeError):
+        vp.prune_vit_mlp_width(m, sparsity=0.1, strategy="act_l2")
+    out = vp.prune_vit_mlp_width(m, sparsity=0.25, strategy="l1", min_remaining=16)          # weight-L1 fallback path
+    assert out is m and m.blocks[0].mlp.fc1.out_features == 96
+
+
+def test_stage2_selection_rules_without_gpu():
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    from ssp2vit.mask_conjunction import Auto2SSPInterface, PruningTypes
+    w, _, z = load_tiny_golden("timm")
+    m = build_from_flat(w, "timm")
+    iface = Auto2SSPInterface(m, None, importance_mode="heuristic")
+    assert iface.att_prune_type is PruningTypes.DEPTH and iface.mlp_prune_type is PruningTypes.WIDTH
+    att, mlp = iface.fit()                                       # dataloader None: heuristic + weight-L1, no GPU needed
+    gold = json.load(open(os.path.join(GOLDEN, "heuristic_depth.json")))
+    assert att.tolist() == gold["4"] and att.dtype == torch.float32
+    assert len(mlp) == 4 and all(torch.equal(t, b.mlp.fc1.weight.abs().sum(1)) for t, b in zip(mlp, m.blocks))
+    res = vp.prune_vit_attention_blocks(m, 0.5, dataloader=None, importance_mode="heuristic", show_progress=False, num_to_prune=2)
+    assert res["pruned_indices"] == z["s2_heur.pruned"].tolist() and res["original_metrics"] is None
+    assert isinstance(m.blocks[0].attn, vp.TimmAttentionBypass)
+    assert torch.equal(m.blocks[0].attn(torch.ones(2, 3)), torch.zeros(2, 3))
+    m = build_from_flat(w, "timm")
+    res = vp.prune_vit_attention_blocks(m, 0.5, selected_indices=[3, 1, 9, -1], num_to_prune=2)
+    assert res["pruned_indices"] == [1, 3]
+    assert vp.prune_vit_attention_blocks(m, 0.0)["pruned_indices"] == []
+    with pytest.raises(AssertionError):
+        vp.prune_vit_attention_blocks(m, 1.0)
+    hf = build_from_flat(w, "hf")
+    vp.prune_vit_attention_blocks(hf, 0.5, selected_indices=[0], num_to_prune=1)
+    out = hf.vit.encoder.layer[0].attention(torch.ones(1, 2, 4), output_attentions=True)
+    assert isinstance(out, tuple) and out[1] is None and not out[0].any()
+
+
+def test_anatomy_adapter_round_trip_and_bypass_detection():
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp, weights as W
+    w, _, _ = load_tiny_golden("timm")
+    for layout in ("timm", "hf"):
+        m = build_from_flat(w, layout)
+        w2 = W.from_module(m)
+        assert w2["layout"] == layout and W.score_site_for(layout) == ("pre_gelu" if layout == "timm" else "post_gelu")
+        for k, v in w.items():
+            if isinstance(v, torch.Tensor):
+                assert torch.equal(w2[k].reshape(v.shape), v), k
+        assert (w2["img"], w2["patch"], w2["dim"], w2["heads"], w2["depth"], w2["classes"]) == (32, 16, 64, 4, 4, 10)
+        vp._apply_bypass(m, 2)
+        w3 = W.from_module(m)
+        assert w3.get("attn_absent.2") and not w3["qkv_w.2"].any() and w3["heads"] == 4
+    with pytest.raises(AttributeError):
+        W.detect_layout(torch.nn.Linear(2, 2))
+
+
+# ------------------------------------------------------------------------------------------ C ABI surface
+def test_library_exports_every_declared_symbol():
+    from ssp2vit import _lib
+    header = open(os.path.join(ROOT, "include", "ssp2vit.h")).read()
+    declared = sorted(set(re.findall(r"\b(ssp2_[a-z0-9_]+)\s*\(", header)))
+    assert declared == sorted(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ssp2_abi_version() == 1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    from ssp2vit._lib import Ssp2Error
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.mask_conjunction import Auto2SSPInterface
+    w, batches, _ = load_tiny_golden("timm")
+    with pytest.raises(Ssp2Error):
+        VitEngine(w)
+    m = build_from_flat(w, "timm")
+    with pytest.raises(Ssp2Error):
+        vp._compute_ffn_activation_importance(m, batches, device="cuda")
+    with pytest.raises(Ssp2Error):
+        vp.evaluate_top1(m, batches, device="cuda")
+    with pytest.raises(Ssp2Error):
+        Auto2SSPInterface(m, batches)._compute_mlp_importance()          # no silent weight-L1 fallback
+    with pytest.raises(Ssp2Error):
+        Auto2SSPInterface(m, batches, error_policy="raise")._compute_att_depth_importance()
+    att = Auto2SSPInterface(m, batches, error_policy="heuristic")._compute_att_depth_importance()
+    assert att.tolist() == [0.0, 1.0, 2.0, 1.0]                          # reference error_policy semantics
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(PKG, "ssp2vit")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), f
+
+
+def test_report_writer(tmp_path):
+    from ssp2vit import vit_pruning as vp
+    rep = {"config": {"model": "x"}, "metrics": {"acc_baseline": 0.5}, "artifacts": {"a": 1},
+           "plan": {"target_sparsity": 0.3, "num_blocks_total": 4, "blocks_to_prune": 1, "stage2_fraction": 0.25,
+                    "per_block_neurons_to_prune": 3, "estimated_total_removed_params": 9, "est_error_params": 1}}
+    out = vp.save_report(rep, str(tmp_path), run_id="t")
+    assert json.load(open(out["json"]))["plan"]["blocks_to_prune"] == 1
+    md = open(out["md"]).read()
+    assert md.startswith("# 2SSP ViT Pruning Report (t)") and "- Blocks to prune (Stage-2): 1 (0.2500)" in md
