@@ -84,24 +84,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
       }
     }
-    // ---- softmax over keys (registers + the other lane half)
+    // ---- softmax over keys (registers + the other lane half).  scale > 0, so the row max is taken on the raw
+    // scores and the scale folds into the exponent: p = exp2((s - max) * scale * log2(e)) = one fma + one v_exp.
+    // Only the last key tile can hold keys >= tokens; they are masked to -inf there (exp2 -> 0).
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-        const float v = key < tokens ? sacc[kt][i] * scale : -INFINITY;
-        sacc[kt][i] = v;
-        mx = fmaxf(mx, v);
+        if (kt == NT - 1) {
+          const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+          if (key >= tokens) sacc[kt][i] = -INFINITY;
+        }
+        mx = fmaxf(mx, sacc[kt][i]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float c2 = scale * 1.44269504088896340736f;
+    const float mc = -mx * c2;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float e = __expf(sacc[kt][i] - mx);
+        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][i], c2, mc));
         sacc[kt][i] = e;
         sum += e;
       }

@@ -122,13 +122,18 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------------ launches
-template <int EPI>
+template <int EPI, int SCORE = 0>
 static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
   if (g.K % GEMM_BK) return fail(SSP2_EINVAL, "GEMM K=%d not a multiple of %d", g.K, GEMM_BK);
   g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
   if (g.tiles_m <= 0 || g.tiles_n <= 0) return fail(SSP2_EINVAL, "empty GEMM");
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    attr_done = true;
+  }
   ProfScope ps(e, klass);
-  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, e->stream, g);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SCORE>), dim3(g.tiles_m * g.tiles_n), dim3(256), GEMM_LDS_BYTES, e->stream, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -137,12 +142,12 @@ static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const flo
                      int out_ld, int rows, int D) {
   ProfScope ps(e, SSP2_K_LN);
   dim3 grid((rows + 3) / 4), blk(256);
-  if (D <= 64 * 4)
-    hipLaunchKernelGGL(layernorm_bf16_kernel<4>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
-  else if (D <= 64 * 12)
-    hipLaunchKernelGGL(layernorm_bf16_kernel<12>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
-  else if (D <= 64 * 32)
-    hipLaunchKernelGGL(layernorm_bf16_kernel<32>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
+  if (D <= 256 * 1)
+    hipLaunchKernelGGL(layernorm_bf16_kernel<1>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
+  else if (D <= 256 * 3)
+    hipLaunchKernelGGL(layernorm_bf16_kernel<3>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
+  else if (D <= 256 * 8)
+    hipLaunchKernelGGL(layernorm_bf16_kernel<8>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
   else
     return fail(SSP2_EINVAL, "LayerNorm width %d > 2048 unsupported", D);
   HIPCHK(hipGetLastError());
@@ -387,7 +392,10 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
     // unfused pre-GELU scoring (models with < 128 tokens): the hook sees fc1's output, fc2 consumes the GELU
     // of it, so the epilogue also stores the pre-activation for the standalone L2 kernel to read.
     f.out2 = (score_site == SSP2_SCORE_PRE_GELU && !fused) ? e->prebuf : nullptr;
-    if ((rc = launch_gemm<EPI_FC1>(e, f, SSP2_K_GEMM_FC1))) return rc;
+    if (f.score_site == 1) rc = launch_gemm<EPI_FC1, 1>(e, f, SSP2_K_GEMM_FC1);
+    else if (f.score_site == 2) rc = launch_gemm<EPI_FC1, 2>(e, f, SSP2_K_GEMM_FC1);
+    else rc = launch_gemm<EPI_FC1, 0>(e, f, SSP2_K_GEMM_FC1);
+    if (rc) return rc;
     if (score_site) {
       float* row = batch_scores + (size_t)l * score_ld;
       if (fused) {

@@ -45,8 +45,9 @@ __global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: fp32 rows -> bf16 rows.  One wave per row, the row lives in registers
-// (two-pass mean / variance in fp32).  in row r is read at x + r*in_stride (in_stride = tokens*dim picks
-// the CLS rows for the classifier head).  D multiple of 64, D <= 64*MAXV.
+// (two-pass mean / variance in fp32), 16-byte loads and 8-byte stores (lane owns float4 chunks lane, lane+64, ..).
+// Row r is read at x + r*in_stride (in_stride = tokens*dim picks the CLS rows for the classifier head).
+// D multiple of 4, D <= 256*MAXV.
 template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, size_t in_stride,
                                                             const float* __restrict__ gamma,
@@ -55,26 +56,38 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + (size_t)row * in_stride;
-  const int nv = D >> 6;
-  float v[MAXV];
+  const f32x4* xr = (const f32x4*)(x + (size_t)row * in_stride);
+  const int nv = D >> 2;                      // float4 chunks in the row
+  f32x4 v[MAXV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if (i < nv) { v[i] = xr[i * 64 + lane]; s += v[i]; }
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) { v[i] = xr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+  }
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if (i < nv) { const float d = v[i] - mean; q += d * d; }
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q += d * d; }
+    }
+  }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
   bf16* yr = y + (size_t)row * out_ld;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if (i < nv) {
-      const int c = i * 64 + lane;
-      yr[c] = (bf16)((v[i] - mean) * rstd * gamma[c] + beta[c]);
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nv) {
+      const f32x4 g4 = ((const f32x4*)gamma)[c], b4 = ((const f32x4*)beta)[c];
+      bf16x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (bf16)((v[i][k] - mean) * rstd * g4[k] + b4[k]);
+      *(bf16x4*)(yr + c * 4) = o;
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

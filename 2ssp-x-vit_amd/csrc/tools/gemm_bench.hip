@@ -1,0 +1,81 @@
+// Standalone micro-benchmark of gemm_bf16_kernel<EPI> on random bf16 data (HIP events, median of rounds).
+//   gemm_bench.bin M N K epi [iters] [tokens]       epi: 0 bf16, 1 resid, 2 fc1(+score), 3 patch, 4 f32
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../gemm.hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+
+template <int EPI, int SCORE = 0> static void launch(const GemmArgs& g, hipStream_t s) {
+  static bool done = false;
+  if (!done) { CK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES)); done = true; }
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SCORE>), dim3(g.tiles_m * g.tiles_n), dim3(256), GEMM_LDS_BYTES, s, g);
+}
+
+int main(int argc, char** argv) {
+  int M = argc > 1 ? atoi(argv[1]) : 12608, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
+  int epi = argc > 4 ? atoi(argv[4]) : 2, iters = argc > 5 ? atoi(argv[5]) : 20, tokens = argc > 6 ? atoi(argv[6]) : 197;
+  int Npad = (N + 127) / 128 * 128;
+  std::vector<uint16_t> hA((size_t)M * K), hW((size_t)Npad * K);
+  srand(1);
+  for (auto& v : hA) v = f2bf((rand() / (float)RAND_MAX) * 2.f - 1.f);
+  for (auto& v : hW) v = f2bf(((rand() / (float)RAND_MAX) * 2.f - 1.f) * 0.05f);
+  bf16 *A, *W, *out; float *bias, *x, *slab, *pos;
+  CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&W, hW.size() * 2)); CK(hipMalloc(&out, (size_t)M * Npad * 2));
+  CK(hipMalloc(&bias, Npad * 4)); CK(hipMalloc(&x, (size_t)(M + M / 196 + 2) * Npad * 4)); CK(hipMalloc(&slab, (size_t)((M + 127) / 128) * 2 * Npad * 4));
+  CK(hipMalloc(&pos, (size_t)200 * Npad * 4));
+  CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(bias, 0, Npad * 4)); CK(hipMemset(x, 0, (size_t)(M + M / 196 + 2) * Npad * 4)); CK(hipMemset(pos, 0, (size_t)200 * Npad * 4));
+  GemmArgs g{};
+  g.A = A; g.lda = K; g.W = W; g.ldw = K; g.bias = bias; g.M = M; g.N = N; g.K = K;
+  g.tiles_m = (M + 127) / 128; g.tiles_n = Npad / 128; g.out = out; g.ldo = Npad; g.x = x; g.ldx = Npad;
+  g.score_site = epi == 2 ? 1 : (epi == 5 ? 2 : 0); g.tokens = tokens; g.slab = slab; g.slab_ld = Npad; g.pos = pos; g.patches = 196; g.group_m = argc > 7 ? atoi(argv[7]) : 0;
+#ifdef GEMM_STAMPS
+  unsigned long long* stamps; CK(hipMalloc(&stamps, (size_t)g.tiles_m * g.tiles_n * 64 * 8)); CK(hipMemset(stamps, 0, (size_t)g.tiles_m * g.tiles_n * 64 * 8));
+  g.stamps = stamps;
+#endif
+  hipStream_t s; CK(hipStreamCreate(&s));
+  auto run = [&]() {
+    switch (epi) { case 0: launch<EPI_BF16>(g, s); break; case 1: launch<EPI_RESID>(g, s); break; case 2: launch<EPI_FC1, 1>(g, s); break; case 5: launch<EPI_FC1, 2>(g, s); break; case 6: launch<EPI_FC1, 0>(g, s); break;
+                   case 3: launch<EPI_PATCH>(g, s); break; default: launch<EPI_F32>(g, s); }
+  };
+  for (int i = 0; i < 3; ++i) run();
+  CK(hipStreamSynchronize(s));
+  std::vector<float> ms(iters);
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < iters; ++i) { CK(hipEventRecord(a, s)); run(); CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms[i], a, b)); }
+  std::sort(ms.begin(), ms.end());
+  double fl = 2.0 * M * (double)N * K;
+  printf("M=%d N=%d K=%d epi=%d blocks=%d  median %.1f us  min %.1f us  -> %.0f TFLOP/s (median) %.0f (min)\n", M, N, K, epi,
+         g.tiles_m * g.tiles_n, ms[iters / 2] * 1e3, ms[0] * 1e3, fl / (ms[iters / 2] * 1e-3) / 1e12, fl / (ms[0] * 1e-3) / 1e12);
+#ifdef GEMM_STAMPS
+  {
+    int nb = g.tiles_m * g.tiles_n, nk = K / 64;
+    std::vector<unsigned long long> h((size_t)nb * 64);
+    CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    double mfma = 0, wait = 0, bar = 0, tot = 0; long cnt = 0;
+    unsigned long long tmin = ~0ULL, tmax = 0;
+    for (int b = 0; b < nb; ++b) {
+      const unsigned long long* t = &h[(size_t)b * 64];
+      tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[60]);
+      unsigned long long prev = t[0];
+      for (int k = 0; k < nk && 3 + 3 * k < 60; ++k) {
+        mfma += (double)(t[1 + 3 * k] - prev); wait += (double)(t[2 + 3 * k] - t[1 + 3 * k]); bar += (double)(t[3 + 3 * k] - t[2 + 3 * k]);
+        prev = t[3 + 3 * k]; ++cnt;
+      }
+      tot += (double)(t[60] - t[0]);
+    }
+    printf("stamps (cycles, wave 0 of every block): per-iteration issue+mfma %.0f  vmcnt-wait %.0f  barrier %.0f ; main loop per block %.0f ; kernel span %.0f\n",
+           mfma / cnt, wait / cnt, bar / cnt, tot / nb, (double)(tmax - tmin));
+    // distribution of block start times (first 16 and a few later)
+    for (int b : {0, 1, 255, 256, 511, 512, 513, 1000, 2000}) if (b < nb) printf("  block %d start %+lld loop %lld\n", b, (long long)(h[(size_t)b * 64] - tmin), (long long)(h[(size_t)b * 64 + 60] - h[(size_t)b * 64]));
+  }
+#endif
+  return 0;
+}
