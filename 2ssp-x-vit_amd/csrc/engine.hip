@@ -356,7 +356,7 @@ int ssp2_embed(ssp2_handle e, const float* pixels_dev, int n, float* x_dev) {
 }
 
 int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const uint8_t* attn_skip, int score_site,
-                int score_chain, float* batch_scores, int score_ld) {
+                int score_chain, int score_group, float* batch_scores, int score_ld) {
   int rc;
   if ((rc = check_n(e, n))) return rc;
   if (!x) return fail(SSP2_EINVAL, "null x");
@@ -364,6 +364,9 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
   if (score_site < 0 || score_site > 2) return fail(SSP2_EINVAL, "bad score_site %d", score_site);
   if (score_site && (!batch_scores || score_ld < e->ld_int_max)) return fail(SSP2_EINVAL, "batch_scores needs ld >= %d", e->ld_int_max);
   const int D = e->d.dim, M = n * e->tokens;
+  const int grp = (score_group <= 0 || score_group > n) ? n : score_group;
+  const int n_groups = (n + grp - 1) / grp;
+  const size_t group_stride = (size_t)e->d.depth * score_ld;
   const bool fused = score_site && e->tokens >= GEMM_BM;   // a 128-row tile then spans at most two samples
   for (int l = l_begin; l < l_end; ++l) {
     Layer& L = e->layers[l];
@@ -402,12 +405,13 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
         ProfScope ps(e, SSP2_K_SCORE_FINISH);
         hipLaunchKernelGGL(score_norms_from_slab_kernel, dim3((L.ld_int + 255) / 256, n), dim3(256), 0, e->stream,
                            e->slab, e->norms, n, e->tokens, L.ld_int, score_chain);
-        hipLaunchKernelGGL(score_colsum_kernel, dim3((L.ld_int + 255) / 256), dim3(256), 0, e->stream, e->norms, row, n, L.ld_int, score_chain);
+        hipLaunchKernelGGL(score_colsum_kernel, dim3((L.ld_int + 255) / 256, n_groups), dim3(256), 0, e->stream, e->norms, row,
+                           group_stride, n, grp, L.ld_int, score_chain);
         HIPCHK(hipGetLastError());
       } else {
         const bf16* seen = (score_site == SSP2_SCORE_PRE_GELU) ? e->prebuf : e->actbuf;
         ProfScope ps(e, SSP2_K_ACT_L2);
-        if ((rc = ssp2_act_l2_accum(e->stream, seen, 0, n, e->tokens, L.d_int, L.ld_int, score_chain, e->norms, row))) return rc;
+        if ((rc = ssp2_act_l2_accum(e->stream, seen, 0, n, e->tokens, L.d_int, L.ld_int, score_chain, grp, e->norms, row, group_stride))) return rc;
       }
     }
     GemmArgs o{};
@@ -439,7 +443,8 @@ int ssp2_head(ssp2_handle e, const float* x, int n, float* logits_dev, int32_t* 
   return 0;
 }
 
-int ssp2_act_l2_accum(void* stream, const void* act, int dtype, int n, int tokens, int d, int ld, int chain, float* norms_ws, float* out) {
+int ssp2_act_l2_accum(void* stream, const void* act, int dtype, int n, int tokens, int d, int ld, int chain, int group,
+                      float* norms_ws, float* out, size_t out_stride) {
   if (!act || !norms_ws || !out) return fail(SSP2_EINVAL, "null device pointer");
   if (n <= 0 || tokens <= 0 || d <= 0 || ld < d || (ld % 8)) return fail(SSP2_EINVAL, "bad shape n=%d tokens=%d d=%d ld=%d (ld multiple of 8, >= d)", n, tokens, d, ld);
   hipStream_t s = (hipStream_t)stream;
@@ -450,7 +455,9 @@ int ssp2_act_l2_accum(void* stream, const void* act, int dtype, int n, int token
     hipLaunchKernelGGL(act_l2_norms_kernel<float>, grid, blk, 0, s, (const float*)act, norms_ws, tokens, ld, chain);
   else
     return fail(SSP2_EINVAL, "dtype %d (0 = bf16, 1 = f32)", dtype);
-  hipLaunchKernelGGL(score_colsum_kernel, dim3((ld + 255) / 256), dim3(256), 0, s, norms_ws, out, n, ld, chain);
+  const int grp = (group <= 0 || group > n) ? n : group;
+  hipLaunchKernelGGL(score_colsum_kernel, dim3((ld + 255) / 256, (n + grp - 1) / grp), dim3(256), 0, s, norms_ws, out, out_stride, n, grp, ld,
+                     chain);
   HIPCHK(hipGetLastError());
   return 0;
 }

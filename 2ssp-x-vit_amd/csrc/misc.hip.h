@@ -110,13 +110,17 @@ __global__ void score_norms_from_slab_kernel(const float* __restrict__ slab, flo
   norms[(size_t)s * ld + j] = nrm;
 }
 
-// step 3 (both paths): out[j] = sum_s norms[s][j], samples in index order (fixed association).
-__global__ void score_colsum_kernel(const float* __restrict__ norms, float* __restrict__ out, int n, int ld, int chain) {
+// step 3 (both paths): out[g][j] = sum over the samples s of group g (group*g <= s < group*(g+1), s < n) of
+// norms[s][j], samples in index order (fixed association).  grid (ld/256, groups).
+__global__ void score_colsum_kernel(const float* __restrict__ norms, float* __restrict__ out, size_t out_stride, int n,
+                                    int group, int ld, int chain) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= ld) return;
+  const int s0 = blockIdx.y * group;
+  const int s1 = min(n, s0 + group);
   float acc = 0.f;
-  for (int s = 0; s < n; ++s) acc += norms[(size_t)s * ld + j];
-  out[j] = chain ? bf16_round(acc) : acc;
+  for (int s = s0; s < s1; ++s) acc += norms[(size_t)s * ld + j];
+  out[(size_t)blockIdx.y * out_stride + j] = chain ? bf16_round(acc) : acc;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -78,9 +78,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_set_stream.argtypes = [vp, vp]
     lib.ssp2_load_tensor.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.c_size_t]
     lib.ssp2_embed.argtypes = [vp, vp, i32, vp]
-    lib.ssp2_layers.argtypes = [vp, vp, i32, i32, i32, C.POINTER(C.c_uint8), i32, i32, vp, i32]
+    lib.ssp2_layers.argtypes = [vp, vp, i32, i32, i32, C.POINTER(C.c_uint8), i32, i32, i32, vp, i32]
     lib.ssp2_head.argtypes = [vp, vp, i32, vp, vp, vp, vp]
-    lib.ssp2_act_l2_accum.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.ssp2_act_l2_accum.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, C.c_size_t]
     lib.ssp2_profile_begin.argtypes = [vp, i32]
     lib.ssp2_profile_end.argtypes = [vp, C.POINTER(C.c_double), i64p]
     lib.ssp2_tokens.argtypes = [vp]

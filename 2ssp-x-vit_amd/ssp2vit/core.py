@@ -4,6 +4,7 @@ reference-named wrappers in `vit_pruning` (live nn.Module in, like the reference
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -25,26 +26,85 @@ def iter_limited(dataloader: Iterable, limit: Optional[int], progress: bool, des
         yield i, batch
 
 
+DEFAULT_CHUNK_IMAGES = int(os.environ.get("SSP2_CHUNK_IMAGES", "256"))
+
+
 def _resolve(engine, min_images: int):
     return engine(min_images) if callable(engine) else engine
 
 
+class _Chunker:
+    """Packs consecutive dataloader batches into one device forward of up to `capacity` images.
+
+    GEMM tiles are 128 rows of (image, token) pairs; one 64-image batch of ViT-B/16 gives 99 row tiles, which fills
+    the 256 CUs unevenly.  Several batches per launch fix the tail and amortise launches.  Batches inside a chunk
+    must all have the size of the first one, except the last (a ragged final batch closes the chunk), so that group
+    g of the chunk is exactly dataloader batch g (needed for the per-batch score sums)."""
+
+    def __init__(self, capacity: int, device):
+        self.capacity, self.device = capacity, device
+        self.items = []          # (global batch index, pixels on device, labels or None)
+        self.count = 0
+
+    def full_for(self, n: int) -> bool:
+        if not self.items:
+            return False
+        g = self.items[0][1].size(0)
+        return n > g or self.count + n > self.capacity or self.items[-1][1].size(0) < g
+
+    def add(self, idx, px, labels=None):
+        self.items.append((idx, px.to(self.device, torch.float32, non_blocking=True),
+                           None if labels is None else labels.to(self.device, torch.int64, non_blocking=True)))
+        self.count += int(px.size(0))
+
+    def take(self):
+        items, self.items, self.count = self.items, [], 0
+        px = items[0][1] if len(items) == 1 else torch.cat([it[1] for it in items], 0)
+        labels = None
+        if items[0][2] is not None:
+            labels = items[0][2] if len(items) == 1 else torch.cat([it[2] for it in items], 0)
+        return [it[0] for it in items], int(items[0][1].size(0)), px, labels
+
+
 @torch.no_grad()
 def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch_limit: Optional[int] = None,
-                  progress: bool = False, score_chain: str = "fp32", process_group=None) -> List[torch.Tensor]:
-    """Reference src/vit_pruning.py:111-201.  `engine`: VitEngine or callable(min_images) -> VitEngine."""
+                  progress: bool = False, score_chain: str = "fp32", process_group=None,
+                  chunk_images: Optional[int] = None) -> List[torch.Tensor]:
+    """Reference src/vit_pruning.py:111-201.  `engine`: VitEngine or callable(min_images) -> VitEngine.
+
+    Default: ONE dataloader batch per forward.  A sample's sum of squares is folded per 128-row GEMM tile, so its
+    fp32 rounding depends on where the sample sits in the launch; one batch per launch pins that position and makes
+    the scores bit-identical for every world size.  `chunk_images` > batch size packs several batches per launch
+    (faster; scores then move by ~1e-7 relative with the packing)."""
     rank, ws = _dist.world(process_group)
+    chunk_images = chunk_images or 0
     local: List[Tuple[int, torch.Tensor]] = []
     n_samples = n_batches = 0
     eng = None
+    ch = None
+
+    def flush():
+        idxs, group, px, _ = ch.take()
+        vec = eng.forward_scores(px, site, score_chain, group)      # [len(idxs), L, ld]
+        for k, i in enumerate(idxs):
+            local.append((i, vec[k]))
+
     for i, batch in iter_limited(dataloader, batch_limit, progress, "S1 activations"):
         px = batch["pixel_values"]
-        n_samples += int(px.size(0)); n_batches += 1
+        n = int(px.size(0))
+        n_samples += n; n_batches += 1
         if not _dist.owns(i, rank, ws):
             continue
-        if eng is None or (callable(engine) and px.size(0) > eng.max_images):
-            eng = _resolve(engine, max(64, int(px.size(0))))
-        local.append((i, eng.forward_scores(px, site, score_chain)))
+        if eng is None or (callable(engine) and n > eng.max_images):
+            if ch is not None and ch.items:
+                flush()
+            eng = _resolve(engine, max(chunk_images, n))
+            ch = _Chunker(min(eng.max_images, max(chunk_images, n)), eng.device)
+        if ch.full_for(n):
+            flush()
+        ch.add(i, px)
+    if ch is not None and ch.items:
+        flush()
 
     vecs = _dist.gather_batch_vectors(local, n_batches, process_group)
     denom = max(1, n_samples)
@@ -52,7 +112,7 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
         return [torch.zeros(d) for d in d_ints]
     if score_chain == "fp32":
         total = torch.zeros_like(vecs[0])
-        for v in vecs:                          # global batch order: identical on every rank / world size
+        for v in vecs:                          # global batch order: identical on every rank / world size / chunking
             total += v
         total = (total / denom).to("cpu")
         return [total[l, :d].clone() for l, d in enumerate(d_ints)]
@@ -71,28 +131,43 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
     return imps
 
 
-@torch.no_grad()
-def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process_group=None,
-                attn_skip: Optional[Sequence[int]] = None) -> Tuple[int, int]:
-    """Reference src/vit_pruning.py:325-373 as integer counts (correct, total)."""
-    rank, ws = _dist.world(process_group)
+def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images):
+    """Yields (engine, pixels, labels) chunks of the batches this rank owns."""
     eng = None
-    correct_dev = None
-    total = 0
-    for i, batch in iter_limited(dataloader, max_batches, progress, "eval"):
+    ch = None
+    for i, batch in iter_limited(dataloader, limit, progress, desc):
         if not _dist.owns(i, rank, ws):
             continue
         px, labels = batch["pixel_values"], batch["labels"]
-        if eng is None:
-            eng = _resolve(engine, max(64, int(px.size(0))))
+        n = int(px.size(0))
+        if eng is None or (callable(engine) and n > eng.max_images):
+            if ch is not None and ch.items:
+                yield (eng,) + ch.take()[2:]
+            eng = _resolve(engine, max(chunk_images, n))
+            ch = _Chunker(min(eng.max_images, max(chunk_images, n)), eng.device)
+        if ch.full_for(n):
+            yield (eng,) + ch.take()[2:]
+        ch.add(i, px, labels)
+    if ch is not None and ch.items:
+        yield (eng,) + ch.take()[2:]
+
+
+@torch.no_grad()
+def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process_group=None,
+                attn_skip: Optional[Sequence[int]] = None, chunk_images: Optional[int] = None) -> Tuple[int, int]:
+    """Reference src/vit_pruning.py:325-373 as integer counts (correct, total)."""
+    rank, ws = _dist.world(process_group)
+    correct_dev = None
+    total = 0
+    for eng, px, labels in _chunks(engine, dataloader, max_batches, progress, "eval", rank, ws,
+                                   chunk_images or DEFAULT_CHUNK_IMAGES):
         if correct_dev is None:
             correct_dev = torch.zeros(1, dtype=torch.int64, device=eng.device)
-        for s in range(0, px.size(0), eng.max_images):
-            chunk = px[s:s + eng.max_images]
-            x = eng.embed(chunk)
-            eng.layers(x, chunk.size(0), 0, eng.depth, attn_skip)
-            eng.head(x, chunk.size(0), labels=labels[s:s + eng.max_images], correct=correct_dev)
-        total += int(labels.size(0))
+        n = int(px.size(0))
+        x = eng.embed(px)
+        eng.layers(x, n, 0, eng.depth, attn_skip)
+        eng.head(x, n, labels=labels, correct=correct_dev)
+        total += n
     counts = torch.tensor([0, total], dtype=torch.int64, device=correct_dev.device if correct_dev is not None else "cpu")
     if correct_dev is not None:
         counts[0] = correct_dev[0]
@@ -104,7 +179,8 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
 
 @torch.no_grad()
 def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional[int] = 5, process_group=None,
-                        removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None):
+                        removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None,
+                        chunk_images: Optional[int] = None):
     """One pass over the eval batches that yields the baseline AND every candidate's correct-count.
 
     The reference deep-copies the model and re-runs the whole forward per candidate (mask_conjunction.py:339-355,
@@ -114,36 +190,28 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
     L(L+1)/2 + L block passes per batch instead of L(L+1).
     Returns (baseline_correct, [candidate_correct per block], total)."""
     rank, ws = _dist.world(process_group)
-    eng = None
     L = depth
     counts_dev = None
     total = 0
     removed = sorted(set(int(r) for r in removed))
     cands = list(range(L)) if candidates is None else [int(c) for c in candidates]
-    for i, batch in iter_limited(dataloader, batch_limit, False, "attn search"):
-        if not _dist.owns(i, rank, ws):
-            continue
-        px_all, labels_all = batch["pixel_values"], batch["labels"]
-        if eng is None:
-            eng = _resolve(engine, max(64, int(px_all.size(0))))
+    for eng, px, labels in _chunks(engine, dataloader, batch_limit, False, "attn search", rank, ws,
+                                   chunk_images or DEFAULT_CHUNK_IMAGES):
         if counts_dev is None:
             counts_dev = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
-        for s in range(0, px_all.size(0), eng.max_images):
-            px = px_all[s:s + eng.max_images]
-            labels = labels_all[s:s + eng.max_images].to(eng.device)
-            n = px.size(0)
-            x = eng.embed(px)
-            cache = {}
-            for l in range(L):
-                if l in cands:
-                    cache[l] = x.clone()
-                eng.layers(x, n, l, l + 1, removed)
-            eng.head(x, n, labels=labels, correct=counts_dev[L:L + 1])
-            for c in cands:
-                xc = cache.pop(c)
-                eng.layers(xc, n, c, L, removed + [c])
-                eng.head(xc, n, labels=labels, correct=counts_dev[c:c + 1])
-        total += int(labels_all.size(0))
+        n = int(px.size(0))
+        x = eng.embed(px)
+        cache = {}
+        for l in range(L):
+            if l in cands:
+                cache[l] = x.clone()
+            eng.layers(x, n, l, l + 1, removed)
+        eng.head(x, n, labels=labels, correct=counts_dev[L:L + 1])
+        for c in cands:
+            xc = cache.pop(c)
+            eng.layers(xc, n, c, L, removed + [c])
+            eng.head(xc, n, labels=labels, correct=counts_dev[c:c + 1])
+        total += n
     if counts_dev is None:
         counts = torch.zeros(L + 2, dtype=torch.int64)
     else:

@@ -84,8 +84,8 @@ class VitEngine:
     def new_x(self, n: int) -> torch.Tensor:
         return torch.empty(n * self.tokens, self.dim, dtype=torch.float32, device=self.device)
 
-    def new_scores(self) -> torch.Tensor:
-        return torch.zeros(self.depth, self.score_ld, dtype=torch.float32, device=self.device)
+    def new_scores(self, groups: int = 1) -> torch.Tensor:
+        return torch.zeros(groups, self.depth, self.score_ld, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ the four device entry points
     def embed(self, pixels: torch.Tensor, x: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -100,14 +100,16 @@ class VitEngine:
 
     def layers(self, x: torch.Tensor, n: int, l_begin: int = 0, l_end: Optional[int] = None,
                attn_skip: Optional[Sequence[int]] = None, score_site: str = "none", score_chain: str = "fp32",
-               batch_scores: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+               batch_scores: Optional[torch.Tensor] = None, score_group: int = 0) -> Optional[torch.Tensor]:
+        """Returns f32 [groups, depth, score_ld] when scoring (groups = ceil(n / score_group), 1 if score_group=0)."""
         l_end = self.depth if l_end is None else l_end
         site = SCORE_SITE[score_site]
+        grp = n if (score_group <= 0 or score_group > n) else score_group
         if site and batch_scores is None:
-            batch_scores = self.new_scores()
+            batch_scores = self.new_scores((n + grp - 1) // grp)
         self._bind_stream()
         check(self.lib.ssp2_layers(self.h, _ptr(x), n, l_begin, l_end, self._skip_array(attn_skip), site,
-                                   SCORE_CHAIN[score_chain], _ptr(batch_scores if site else None), self.score_ld))
+                                   SCORE_CHAIN[score_chain], grp, _ptr(batch_scores if site else None), self.score_ld))
         return batch_scores if site else None
 
     def head(self, x: torch.Tensor, n: int, labels: Optional[torch.Tensor] = None,
@@ -132,18 +134,20 @@ class VitEngine:
         ws = torch.empty(n, d, dtype=torch.float32, device=act.device)
         out = torch.empty(d, dtype=torch.float32, device=act.device)
         check(self.lib.ssp2_act_l2_accum(C.c_void_p(torch.cuda.current_stream(act.device).cuda_stream), _ptr(act), dtype,
-                                         n, t, d, d, SCORE_CHAIN[score_chain], _ptr(ws), _ptr(out)))
+                                         n, t, d, d, SCORE_CHAIN[score_chain], 0, _ptr(ws), _ptr(out), d))
         return out
 
     # ------------------------------------------------------------------ compositions used by the host API
-    def forward_scores(self, pixels: torch.Tensor, score_site: str, score_chain: str = "fp32") -> torch.Tensor:
-        """One calibration batch: returns f32 [depth, score_ld], row l = sum over the batch's samples of the
-        per-sample token-L2 of block l's FFN activation (reference hook body, src/vit_pruning.py:151-152)."""
+    def forward_scores(self, pixels: torch.Tensor, score_site: str, score_chain: str = "fp32",
+                       group: int = 0) -> torch.Tensor:
+        """One forward over `pixels` (one or several dataloader batches of `group` images each, concatenated).
+        Returns f32 [n_groups, depth, score_ld]; entry [g, l] = sum over group g's samples of the per-sample
+        token-L2 of block l's FFN activation (reference hook body, src/vit_pruning.py:151-152)."""
         n = pixels.shape[0]
-        if n > self.max_images:   # one canonical batch per call keeps the sample order of the sum fixed
-            raise Ssp2Error(f"batch of {n} images exceeds engine capacity {self.max_images}")
+        if n > self.max_images:
+            raise Ssp2Error(f"chunk of {n} images exceeds engine capacity {self.max_images}")
         x = self.embed(pixels)
-        return self.layers(x, n, 0, self.depth, None, score_site, score_chain)
+        return self.layers(x, n, 0, self.depth, None, score_site, score_chain, None, group)
 
     def forward_logits(self, pixels: torch.Tensor, attn_skip: Optional[Sequence[int]] = None) -> torch.Tensor:
         outs = []

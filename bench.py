@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--calib", type=int, default=512, help="calibration images per GPU")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--eval-batches", type=int, default=5)
+    ap.add_argument("--calib-chunk", type=int, default=0, help="images per stage-1 forward (0 = one batch; see core.stage1_scores)")
     ap.add_argument("--target", type=float, default=0.375)
     ap.add_argument("--cpu-sample", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,7 +123,7 @@ def main():
     img, patch, dim, heads, d_int, depth = VIT_CONFIGS[args.model]
     tokens = (img // patch) ** 2 + 1
     weights = synthetic_weights(args.model, classes=1000, seed=0, std=0.02, eps=1e-6, spread=4.0)
-    eng = VitEngine(weights, device=dev, max_images=args.batch)
+    eng = VitEngine(weights, device=dev, max_images=max(args.batch, args.eval_batches * args.batch, args.calib_chunk))
     d_ints = [d_int] * depth
     plan = plan_from_stats(stats_from_shapes(dim, depth, d_int, 1000, tokens, patch), args.target, min_remaining=512)
 
@@ -140,8 +141,10 @@ def main():
     n_eval = args.eval_batches * args.batch
 
     def step():
-        imps = core.stage1_scores(eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg)
-        base, cand, total = core.depth_search_counts(eng, eval_loader, depth, batch_limit=None, process_group=pg)
+        imps = core.stage1_scores(eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
+                                  chunk_images=args.calib_chunk)
+        base, cand, total = core.depth_search_counts(eng, eval_loader, depth, batch_limit=None, process_group=pg,
+                                                     chunk_images=n_eval)
         impact = torch.tensor(core.impacts_from_counts(base, cand, total), dtype=torch.float32)
         masks = []
         t = plan.per_block_neurons_to_prune
@@ -175,7 +178,7 @@ def main():
 
     # stage-1-only rate (secondary figure, separate timed loop so the headline region stays untouched)
     sync_all(); t1 = time.perf_counter()
-    core.stage1_scores(eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg)
+    core.stage1_scores(eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg, chunk_images=args.calib_chunk)
     sync_all(); s1_s = time.perf_counter() - t1
 
     el = torch.tensor([elapsed, s1_s], dtype=torch.float64, device=dev)

@@ -83,12 +83,15 @@ int ssp2_embed(ssp2_handle h, const float* pixels_dev, int n, float* x_dev);
 /* a3/a2/a6: run encoder blocks [l_begin, l_end) in place on the residual stream x_dev [n*N, dim].
  *   attn_skip      host bytes [depth] or NULL; attn_skip[l]!=0 == the reference's zero-output attention
  *                  bypass (src/vit_pruning.py:416-429): the block computes x <- x + MLP(LN2(x)) only.
- *   score_site     SSP2_SCORE_*: if not NONE, row l of batch_scores_dev receives
- *                  sum_{s<n} || act_l[s,:,j] ||_2 for this call's n samples (the hook body, :151-152),
- *                  samples added in index order (deterministic, independent of launch geometry).
- *   batch_scores_dev f32 [depth, score_ld] (rows outside [l_begin,l_end) untouched), score_ld >= max d_int. */
+ *   score_site     SSP2_SCORE_*: if not NONE, the call's n samples are cut into groups of score_group
+ *                  consecutive samples (= the reference dataloader's batches; the last group may be short) and
+ *                  batch_scores_dev[g][l][:] receives sum_{s in group g} || act_l[s,:,j] ||_2 (the hook body,
+ *                  :151-152), samples added in index order (deterministic, independent of launch geometry and
+ *                  of how many batches share one call).
+ *   batch_scores_dev f32 [ceil(n/score_group), depth, score_ld] (rows outside [l_begin,l_end) untouched),
+ *                  score_ld >= max d_int;  score_group <= 0 means one group of n. */
 int ssp2_layers(ssp2_handle h, float* x_dev, int n, int l_begin, int l_end, const uint8_t* attn_skip,
-                int score_site, int score_chain, float* batch_scores_dev, int score_ld);
+                int score_site, int score_chain, int score_group, float* batch_scores_dev, int score_ld);
 
 /* a3 tail + a4: final LayerNorm on the CLS rows, classifier, first-max-index argmax (torch.argmax rule),
  * comparison with labels.  Any of logits_dev [n,classes] f32, pred_dev [n] i32, labels_dev [n] i64 +
@@ -98,10 +101,11 @@ int ssp2_head(ssp2_handle h, const float* x_dev, int n, float* logits_dev, int32
 
 /* a2 standalone (the hook body on an activation tensor that already sits in HBM):
  *   act_dev bf16 (dtype 0) or f32 (dtype 1), [n, tokens, ld] with the first d columns used;
- *   out_dev f32 [d] = sum_s sqrt(sum_t act[s,t,j]^2); norms_ws_dev f32 [n, d] scratch.
+ *   out_dev f32 [ceil(n/group), out_stride] : out[g][j] = sum_{s in group g} sqrt(sum_t act[s,t,j]^2)
+ *   (group <= 0: one group of n); norms_ws_dev f32 [n, ld] scratch.
  * HBM-bound: n*tokens*d*sizeof(act) bytes read once. */
 int ssp2_act_l2_accum(void* hip_stream, const void* act_dev, int dtype, int n, int tokens, int d, int ld,
-                      int score_chain, float* norms_ws_dev, float* out_dev);
+                      int score_chain, int group, float* norms_ws_dev, float* out_dev, size_t out_stride);
 
 /* per-kernel-class HIP-event timing (bench.py roofline leg).  klass: see SSP2_K_* */
 enum { SSP2_K_GEMM_FC1 = 0, SSP2_K_GEMM_FC2, SSP2_K_GEMM_QKV, SSP2_K_GEMM_PROJ, SSP2_K_GEMM_PATCH,

@@ -41,11 +41,11 @@ for layout, site in (("timm", "pre_gelu"), ("hf", "post_gelu")):
     print(f"[tiny {layout}]")
     stats("logits", lg, ref)
     print("   argmax agree:", (lg.argmax(-1).cpu() == ref.float().argmax(-1)).float().mean().item())
-    sc = eng.forward_scores(px.cuda(), site, "fp32")
+    sc = eng.forward_scores(px.cuda(), site, "fp32")[0]
     refs = ref_cpu.ffn_activation_importance(model, [{"pixel_values": px}], chain="fp32")
     for l in range(4):
         stats(f"score L{l}", sc[l, :128] / px.shape[0], refs[l])
-    sc2 = eng.forward_scores(px.cuda(), site, "bf16_ref")
+    sc2 = eng.forward_scores(px.cuda(), site, "bf16_ref")[0]
     refb = ref_cpu.ffn_activation_importance(model, [{"pixel_values": px}], batch_limit=1, chain="autocast")
     for l in range(4):
         a = (sc2[l, :128].cpu() ).to(torch.bfloat16) / px.shape[0]
@@ -64,14 +64,14 @@ model = build_from_flat(w, "timm")
 g = torch.Generator().manual_seed(1)
 px = torch.randn(16, 3, 224, 224, generator=g)
 eng = VitEngine(w, max_images=16)
-t0 = time.time(); sc = eng.forward_scores(px.cuda(), "pre_gelu", "fp32"); torch.cuda.synchronize(); print("gpu time first", time.time() - t0)
+t0 = time.time(); sc = eng.forward_scores(px.cuda(), "pre_gelu", "fp32")[0]; torch.cuda.synchronize(); print("gpu time first", time.time() - t0)
 t0 = time.time(); refs = ref_cpu.ffn_activation_importance(model, [{"pixel_values": px}], chain="fp32"); print("cpu time", time.time() - t0)
 print("[vit_tiny16 fused pre_gelu]")
 for l in (0, 5, 11):
     stats(f"score L{l}", sc[l, :768] / 16, refs[l])
 lg = eng.forward_logits(px.cuda()); ref = ref_cpu.logits_of(model, px)
 stats("logits", lg, ref)
-sc_b = eng.forward_scores(px.cuda(), "pre_gelu", "bf16_ref")
+sc_b = eng.forward_scores(px.cuda(), "pre_gelu", "bf16_ref")[0]
 z = dict(np.load(os.path.join(ROOT, "tests", "golden", "vit_tiny16_stage1.npz")))
 # golden used 2 batches of 16: batch 0 == px here; replicate chain for batch 0 only via oracle
 refb = ref_cpu.ffn_activation_importance(model, [{"pixel_values": px}], chain="autocast")
@@ -80,10 +80,10 @@ for l in (0, 5, 11):
     ulp = (a.view(torch.int16).int() - refb[l].view(torch.int16).int()).abs()
     print(f"  bf16_ref L{l}: max ulp diff {ulp.max().item()} exact {(ulp==0).float().mean().item():.3f}")
 # determinism
-sc2 = eng.forward_scores(px.cuda(), "pre_gelu", "fp32")
+sc2 = eng.forward_scores(px.cuda(), "pre_gelu", "fp32")[0]
 print("deterministic:", torch.equal(sc, sc2))
 # post-gelu fused
-sc_p = eng.forward_scores(px.cuda(), "post_gelu", "fp32")
+sc_p = eng.forward_scores(px.cuda(), "post_gelu", "fp32")[0]
 mh = build_from_flat(dict(w, eps=1e-6), "hf")
 refp = ref_cpu.ffn_activation_importance(mh, [{"pixel_values": px}], chain="fp32")
 for l in (0, 11):

@@ -53,10 +53,15 @@ class OracleBackedEngine:
         return lg, lg.argmax(-1), correct
 
     @torch.no_grad()
-    def forward_scores(self, px, site, chain):
+    def forward_scores(self, px, site, chain, group=0):
         from oracle import ref_cpu
-        imps = ref_cpu.ffn_activation_importance(self.m, [{"pixel_values": px}], chain="fp32")
-        return torch.stack([t * px.shape[0] for t in imps])     # un-normalised per-batch sums [L, d_int]
+        group = group if group and group > 0 else px.shape[0]
+        out = []
+        for s in range(0, px.shape[0], group):                   # one row of un-normalised sums per batch
+            part = px[s:s + group]
+            imps = ref_cpu.ffn_activation_importance(self.m, [{"pixel_values": part}], chain="fp32")
+            out.append(torch.stack([t * part.shape[0] for t in imps]))
+        return torch.stack(out)                                  # [groups, L, d_int]
 
 
 def _free_port():

@@ -113,11 +113,11 @@ def test_tiny_logits_scores_and_skip_vs_oracle(gpu, layout):
     # stage-1 scores, both chains (5 tokens < 128: the UNFUSED path, standalone L2 kernel on the stored activation)
     px = batches[0]["pixel_values"]
     ref32 = ref_cpu.ffn_activation_importance(model, [batches[0]], chain="fp32")
-    got = eng.forward_scores(px.to(gpu), SITE[layout], "fp32").cpu() / px.shape[0]
+    got = eng.forward_scores(px.to(gpu), SITE[layout], "fp32")[0].cpu() / px.shape[0]
     for l in range(4):
         assert torch.allclose(got[l, :128], ref32[l], rtol=2e-3, atol=1e-4)
     refb = [bf16_from_bits(z[f"s1_imp_limit1_bf16bits.{l}"]) for l in range(4)]     # REAL reference output
-    gotb = eng.forward_scores(px.to(gpu), SITE[layout], "bf16_ref").cpu()
+    gotb = eng.forward_scores(px.to(gpu), SITE[layout], "bf16_ref")[0].cpu()
     for l in range(4):
         a = gotb[l, :128].to(torch.bfloat16) / px.shape[0]
         ulp = (a.view(torch.int16).int() - refb[l].view(torch.int16).int()).abs()
@@ -167,9 +167,9 @@ def test_fused_epilogue_equals_unfused_kernel_bitwise_inputs(gpu):
     eng = VitEngine(w, max_images=3)
     g = torch.Generator().manual_seed(5)
     px = torch.randn(3, 3, 224, 224, generator=g).to(gpu)
-    fused = eng.forward_scores(px, "post_gelu", "fp32")
+    fused = eng.forward_scores(px, "post_gelu", "fp32")[0]
     # per-image calls exercise n=1 (a single sample, tiles never straddle) and must add up to the batch result
-    parts = [eng.forward_scores(px[i:i + 1], "post_gelu", "fp32") for i in range(3)]
+    parts = [eng.forward_scores(px[i:i + 1], "post_gelu", "fp32")[0] for i in range(3)]
     seq = parts[0].clone()
     for p in parts[1:]:
         seq += p
@@ -276,3 +276,33 @@ def test_copy_mode_selection_and_width_prune_end_to_end(gpu):
                                         importance_mode="copy", show_progress=False, num_to_prune=2)
     assert len(out["pruned_indices"]) == 2 and out["original_metrics"] is not None and out["final_metrics"] is not None
     vp.release_engines()
+
+
+def test_eval_chunking_is_exact_and_stage1_packing_is_close(gpu):
+    """Stage-2 / top-1 counts are integers: packing several dataloader batches into one forward must not change
+    them.  Stage-1 packing (opt-in) keeps per-batch groups and may move scores only at fp32 rounding level."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import core, vit_pruning as vp
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=4, std=0.05, eps=1e-6, bias_std=0.02)
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for n in (8, 8, 8, 5):                                       # ragged last batch
+        batches.append({"pixel_values": torch.randn(n, 3, 224, 224, generator=g),
+                        "labels": torch.randint(0, 10, (n,), generator=g)})
+    eng = VitEngine(w, max_images=32)
+    one = core.depth_search_counts(eng, batches, 12, batch_limit=None, chunk_images=8)
+    packed = core.depth_search_counts(eng, batches, 12, batch_limit=None, chunk_images=32)
+    assert one == packed and one[2] == 29
+    assert core.top1_counts(eng, batches, chunk_images=8) == core.top1_counts(eng, batches, chunk_images=32)
+    d_ints = [768] * 12
+    a = core.stage1_scores(eng, batches, d_ints, "pre_gelu")                       # one batch per forward
+    b = core.stage1_scores(eng, batches, d_ints, "pre_gelu", chunk_images=32)      # 4 batches in one forward
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=1e-5, atol=0)
+    c = core.stage1_scores(eng, batches, d_ints, "pre_gelu", score_chain="bf16_ref", chunk_images=32)
+    d = core.stage1_scores(eng, batches, d_ints, "pre_gelu", score_chain="bf16_ref")
+    for x, y in zip(c, d):
+        ulp = (x.view(torch.int16).int() - y.view(torch.int16).int()).abs()
+        assert int(ulp.max()) <= 1
