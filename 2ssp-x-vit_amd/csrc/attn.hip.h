@@ -15,9 +15,14 @@
 #pragma once
 #include "common.hip.h"
 
-template <int DH, int NT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out,
-                                                      int ldo, int tokens, int dim, float scale) {
+// CLS_ONLY (evaluation tail): only query 0 of every image is needed.  q then comes from a compact [n, dim] buffer
+// (q_img_stride = dim, q_ld = 0: the whole 32-query tile reads the CLS row) and only row 0 is stored, into a compact
+// [n, dim] output.  The arithmetic for query 0 is the same instruction sequence as in the full kernel, so the tail
+// is bit-identical to running the whole block.
+template <int DH, int NT, bool CLS_ONLY = false>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, int ld, const bf16* __restrict__ qsrc,
+                                                      size_t q_img_stride, int q_ld, bf16* __restrict__ out,
+                                                      size_t o_img_stride, int ldo, int tokens, int dim, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DT = (DH + 31) / 32;     // 32-row tiles of the O^T output (d_h padded up)
   constexpr int KS = DH / 16;            // k-steps of the QK^T product
@@ -64,10 +69,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
   const int v_lane_off = (4 * lh + tr_q) * VSB + (16 * tr_g + 4 * tr_p) * 2;
 
-  for (int qt = wave; qt < NT; qt += 4) {            // wave-uniform trip count: EXEC stays full
+  const bf16* qbase = qsrc + (size_t)img * q_img_stride + head * DH;
+  for (int qt = wave; qt < (CLS_ONLY ? 1 : NT); qt += 4) {   // wave-uniform trip count: EXEC stays full
     const int q = qt * 32 + l31;
     const int qc = q < tokens ? q : tokens - 1;
-    const bf16* qp = base + (size_t)qc * ld + 8 * lh;
+    const bf16* qp = qbase + (size_t)qc * q_ld + 8 * lh;
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
@@ -141,8 +147,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       }
     }
     // ---- store: lane <-> query row, 4 consecutive d_h per 8-byte store
-    if (q < tokens) {
-      bf16* op = out + ((size_t)img * tokens + q) * ldo + head * DH;
+    if (CLS_ONLY ? (q == 0) : (q < tokens)) {
+      bf16* op = out + (size_t)img * o_img_stride + (size_t)q * ldo + head * DH;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll

@@ -81,6 +81,9 @@ struct ssp2_engine {
   // workspace (sized for max_images)
   bf16 *a_pe = nullptr, *hbuf = nullptr, *qkvbuf = nullptr, *obuf = nullptr, *actbuf = nullptr, *cls_h = nullptr;
   bf16* prebuf = nullptr;   // pre-GELU copy, only for models with < 128 tokens (unfused scoring)
+  // evaluation tail (last block on the CLS rows only)
+  float* x_cls = nullptr;
+  bf16 *q_cls = nullptr, *o_cls = nullptr, *h_cls = nullptr, *act_cls = nullptr;
   float *slab = nullptr, *norms = nullptr, *logits = nullptr;
 
   // profiling
@@ -154,24 +157,29 @@ static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const flo
   return 0;
 }
 
-template <int DH, int NT>
+template <int DH, int NT, bool CLS>
 static int launch_attn_t(ssp2_engine* e, int n) {
   constexpr int smem = NT * 32 * (DH * 2 + 16) + NT * 32 * 192;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    HIPCHK(hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, NT, CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_done = true;
   }
   ProfScope ps(e, SSP2_K_ATTN);
-  hipLaunchKernelGGL((attn_fwd_kernel<DH, NT>), dim3(e->d.heads, n), dim3(256), smem, e->stream, e->qkvbuf,
-                     3 * e->d.dim, e->obuf, e->d.dim, e->tokens, e->d.dim, 1.0f / sqrtf((float)DH));
+  const int D = e->d.dim, ld = 3 * D;
+  if (CLS)   // q from the compact CLS projection, only row 0 kept, compact [n, D] output
+    hipLaunchKernelGGL((attn_fwd_kernel<DH, NT, true>), dim3(e->d.heads, n), dim3(256), smem, e->stream, e->qkvbuf, ld, e->q_cls,
+                       (size_t)D, 0, e->o_cls, (size_t)D, D, e->tokens, D, 1.0f / sqrtf((float)DH));
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<DH, NT, false>), dim3(e->d.heads, n), dim3(256), smem, e->stream, e->qkvbuf, ld, e->qkvbuf,
+                       (size_t)e->tokens * ld, ld, e->obuf, (size_t)e->tokens * D, D, e->tokens, D, 1.0f / sqrtf((float)DH));
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-static int launch_attn(ssp2_engine* e, int n) {
+static int launch_attn(ssp2_engine* e, int n, bool cls_only = false) {
   const int nt = (e->tokens + 31) / 32;
-#define ATTN_CASE(DH_, NT_) if (e->dh == DH_ && nt == NT_) return launch_attn_t<DH_, NT_>(e, n)
+#define ATTN_CASE(DH_, NT_) if (e->dh == DH_ && nt == NT_) return cls_only ? launch_attn_t<DH_, NT_, true>(e, n) : launch_attn_t<DH_, NT_, false>(e, n)
   ATTN_CASE(64, 7);   // 224/16: 197 tokens (Ti/S/B/L)
   ATTN_CASE(80, 9);   // 224/14: 257 tokens (H/14)
   ATTN_CASE(16, 1);   // reference smoke config: 32/16, 5 tokens
@@ -247,6 +255,11 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
   TRY(dalloc(e, &e->slab, tiles_m * 2 * e->ld_int_max, true));
   TRY(dalloc(e, &e->norms, (size_t)d.max_images * e->ld_int_max, true));
   TRY(dalloc(e, &e->cls_h, (size_t)d.max_images * d.dim, true));
+  TRY(dalloc(e, &e->x_cls, (size_t)d.max_images * d.dim, true));
+  TRY(dalloc(e, &e->q_cls, (size_t)d.max_images * d.dim, true));
+  TRY(dalloc(e, &e->o_cls, (size_t)d.max_images * d.dim, true));
+  TRY(dalloc(e, &e->h_cls, (size_t)d.max_images * d.dim, true));
+  TRY(dalloc(e, &e->act_cls, (size_t)d.max_images * e->ld_int_max, true));
   TRY(dalloc(e, &e->logits, (size_t)d.max_images * d.classes, true));
 #undef TRY
   *out = e;
@@ -422,13 +435,12 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
   return 0;
 }
 
-int ssp2_head(ssp2_handle e, const float* x, int n, float* logits_dev, int32_t* pred, const int64_t* labels, int64_t* correct) {
+static int head_impl(ssp2_engine* e, const float* x, size_t in_stride, int n, float* logits_dev, int32_t* pred, const int64_t* labels,
+                     int64_t* correct) {
   int rc;
-  if ((rc = check_n(e, n))) return rc;
-  if (!x) return fail(SSP2_EINVAL, "null x");
   if (!(e->misc_set[2] && e->misc_set[3] && e->head.w_set && e->head.b_set)) return fail(SSP2_ESTATE, "final norm / head weights not loaded");
   const int D = e->d.dim;
-  if ((rc = launch_ln(e, x, (size_t)e->tokens * D, e->lnf_g, e->lnf_b, e->cls_h, D, n, D))) return rc;
+  if ((rc = launch_ln(e, x, in_stride, e->lnf_g, e->lnf_b, e->cls_h, D, n, D))) return rc;
   float* lg = logits_dev ? logits_dev : e->logits;
   GemmArgs g{};
   g.A = e->cls_h; g.lda = D; g.W = e->head.w; g.ldw = e->head.ld; g.bias = e->head.b;
@@ -441,6 +453,54 @@ int ssp2_head(ssp2_handle e, const float* x, int n, float* logits_dev, int32_t* 
     HIPCHK(hipGetLastError());
   }
   return 0;
+}
+
+int ssp2_head(ssp2_handle e, const float* x, int n, float* logits_dev, int32_t* pred, const int64_t* labels, int64_t* correct) {
+  int rc;
+  if ((rc = check_n(e, n))) return rc;
+  if (!x) return fail(SSP2_EINVAL, "null x");
+  return head_impl(e, x, (size_t)e->tokens * e->d.dim, n, logits_dev, pred, labels, correct);
+}
+
+int ssp2_tail(ssp2_handle e, const float* x, int n, int attn_skip_last, float* logits_dev, int32_t* pred, const int64_t* labels,
+              int64_t* correct) {
+  int rc;
+  if ((rc = check_n(e, n))) return rc;
+  if (!x) return fail(SSP2_EINVAL, "null x");
+  const int D = e->d.dim, M = n * e->tokens, l = e->d.depth - 1;
+  Layer& L = e->layers[l];
+  if (!(L.ln_set[2] && L.ln_set[3] && L.fc1.w_set && L.fc1.b_set && L.fc2.w_set && L.fc2.b_set)) return fail(SSP2_ESTATE, "last layer MLP weights not loaded");
+  // x_cls <- CLS rows of x (x itself is left untouched)
+  HIPCHK(hipMemcpy2DAsync(e->x_cls, (size_t)D * 4, x, (size_t)e->tokens * D * 4, (size_t)D * 4, n, hipMemcpyDeviceToDevice, e->stream));
+  if (!attn_skip_last) {
+    if (!(L.ln_set[0] && L.ln_set[1] && L.qkv.w_set && L.qkv.b_set && L.proj.w_set && L.proj.b_set)) return fail(SSP2_ESTATE, "last layer attention weights not loaded");
+    // keys / values need every token; the query, the out-projection and the MLP only the CLS row
+    if ((rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, e->hbuf, D, M, D))) return rc;
+    GemmArgs kv{};
+    kv.A = e->hbuf; kv.lda = D; kv.W = L.qkv.w + (size_t)D * L.qkv.ld; kv.ldw = L.qkv.ld; kv.bias = L.qkv.b + D;
+    kv.M = M; kv.N = 2 * D; kv.K = D; kv.tiles_n = (2 * D + GEMM_BN - 1) / GEMM_BN; kv.out = e->qkvbuf + D; kv.ldo = 3 * D;
+    if ((rc = launch_gemm<EPI_BF16>(e, kv, SSP2_K_GEMM_QKV))) return rc;
+    if ((rc = launch_ln(e, x, (size_t)e->tokens * D, L.ln1_g, L.ln1_b, e->h_cls, D, n, D))) return rc;
+    GemmArgs q{};
+    q.A = e->h_cls; q.lda = D; q.W = L.qkv.w; q.ldw = L.qkv.ld; q.bias = L.qkv.b;
+    q.M = n; q.N = D; q.K = D; q.tiles_n = (D + GEMM_BN - 1) / GEMM_BN; q.out = e->q_cls; q.ldo = D;
+    if ((rc = launch_gemm<EPI_BF16>(e, q, SSP2_K_GEMM_QKV))) return rc;
+    if ((rc = launch_attn(e, n, true))) return rc;
+    GemmArgs p{};
+    p.A = e->o_cls; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.bias = L.proj.b;
+    p.M = n; p.N = D; p.K = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = e->x_cls; p.ldx = D;
+    if ((rc = launch_gemm<EPI_RESID>(e, p, SSP2_K_GEMM_PROJ))) return rc;
+  }
+  if ((rc = launch_ln(e, e->x_cls, D, L.ln2_g, L.ln2_b, e->h_cls, D, n, D))) return rc;
+  GemmArgs f{};
+  f.A = e->h_cls; f.lda = D; f.W = L.fc1.w; f.ldw = L.fc1.ld; f.bias = L.fc1.b;
+  f.M = n; f.N = L.ld_int; f.K = D; f.tiles_n = L.fc1.rows_pad / GEMM_BN; f.out = e->act_cls; f.ldo = L.ld_int;
+  if ((rc = launch_gemm<EPI_FC1, 0>(e, f, SSP2_K_GEMM_FC1))) return rc;
+  GemmArgs o{};
+  o.A = e->act_cls; o.lda = L.ld_int; o.W = L.fc2.w; o.ldw = L.fc2.ld; o.bias = L.fc2.b;
+  o.M = n; o.N = D; o.K = L.ld_int; o.tiles_n = L.fc2.rows_pad / GEMM_BN; o.x = e->x_cls; o.ldx = D;
+  if ((rc = launch_gemm<EPI_RESID>(e, o, SSP2_K_GEMM_FC2))) return rc;
+  return head_impl(e, e->x_cls, (size_t)D, n, logits_dev, pred, labels, correct);
 }
 
 int ssp2_act_l2_accum(void* stream, const void* act, int dtype, int n, int tokens, int d, int ld, int chain, int group,

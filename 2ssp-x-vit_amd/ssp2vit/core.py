@@ -165,8 +165,8 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
             correct_dev = torch.zeros(1, dtype=torch.int64, device=eng.device)
         n = int(px.size(0))
         x = eng.embed(px)
-        eng.layers(x, n, 0, eng.depth, attn_skip)
-        eng.head(x, n, labels=labels, correct=correct_dev)
+        eng.layers(x, n, 0, eng.depth - 1, attn_skip)
+        eng.tail(x, n, attn_skip, labels=labels, correct=correct_dev)      # last block + head on the CLS rows
         total += n
     counts = torch.tensor([0, total], dtype=torch.int64, device=correct_dev.device if correct_dev is not None else "cpu")
     if correct_dev is not None:
@@ -202,15 +202,19 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
         n = int(px.size(0))
         x = eng.embed(px)
         cache = {}
-        for l in range(L):
+        for l in range(L - 1):
             if l in cands:
                 cache[l] = x.clone()
             eng.layers(x, n, l, l + 1, removed)
-        eng.head(x, n, labels=labels, correct=counts_dev[L:L + 1])
+        # x now enters the last block: every pass finishes with the CLS-only tail, which leaves x untouched
+        eng.tail(x, n, removed, labels=labels, correct=counts_dev[L:L + 1])
         for c in cands:
+            if c == L - 1:
+                eng.tail(x, n, removed + [c], labels=labels, correct=counts_dev[c:c + 1])
+                continue
             xc = cache.pop(c)
-            eng.layers(xc, n, c, L, removed + [c])
-            eng.head(xc, n, labels=labels, correct=counts_dev[c:c + 1])
+            eng.layers(xc, n, c, L - 1, removed + [c])
+            eng.tail(xc, n, removed + [c], labels=labels, correct=counts_dev[c:c + 1])
         total += n
     if counts_dev is None:
         counts = torch.zeros(L + 2, dtype=torch.int64)

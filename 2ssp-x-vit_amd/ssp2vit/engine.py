@@ -125,6 +125,23 @@ class VitEngine:
                                  _ptr(correct if labels is not None else None)))
         return logits, pred, correct
 
+    def tail(self, x: torch.Tensor, n: int, attn_skip: Optional[Sequence[int]] = None,
+             labels: Optional[torch.Tensor] = None, correct: Optional[torch.Tensor] = None, want_logits: bool = False,
+             want_pred: bool = False):
+        """Last encoder block + head on the CLS rows only (x must hold the residual stream ENTERING the last block;
+        it is not modified).  Same results, bit for bit, as layers(x, depth-1, depth) + head(x)."""
+        logits = torch.empty(n, self.classes, dtype=torch.float32, device=self.device) if want_logits else None
+        pred = torch.empty(n, dtype=torch.int32, device=self.device) if want_pred else None
+        if labels is not None:
+            labels = labels.to(self.device, torch.int64, non_blocking=True).contiguous()
+            if correct is None:
+                correct = torch.zeros(1, dtype=torch.int64, device=self.device)
+        skip_last = bool(self.absent[self.depth - 1]) or (attn_skip is not None and (self.depth - 1) in [int(i) for i in attn_skip])
+        self._bind_stream()
+        check(self.lib.ssp2_tail(self.h, _ptr(x), n, int(skip_last), _ptr(logits), _ptr(pred), _ptr(labels),
+                                 _ptr(correct if labels is not None else None)))
+        return logits, pred, correct
+
     def act_l2_accum(self, act: torch.Tensor, score_chain: str = "fp32") -> torch.Tensor:
         """Standalone hook-body kernel: act [n, tokens, d] (bf16 or f32, contiguous, d % 8 == 0) -> f32 [d]."""
         if act.dim() != 3 or not act.is_contiguous() or act.device.type != "cuda":
@@ -154,8 +171,8 @@ class VitEngine:
         for s in range(0, pixels.shape[0], self.max_images):
             chunk = pixels[s:s + self.max_images]
             x = self.embed(chunk)
-            self.layers(x, chunk.shape[0], 0, self.depth, attn_skip)
-            outs.append(self.head(x, chunk.shape[0], want_logits=True)[0])
+            self.layers(x, chunk.shape[0], 0, self.depth - 1, attn_skip)
+            outs.append(self.tail(x, chunk.shape[0], attn_skip, want_logits=True)[0])
         return torch.cat(outs, 0)
 
     def profile(self, klass: str):

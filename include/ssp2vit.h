@@ -99,6 +99,14 @@ int ssp2_layers(ssp2_handle h, float* x_dev, int n, int l_begin, int l_end, cons
 int ssp2_head(ssp2_handle h, const float* x_dev, int n, float* logits_dev, int32_t* pred_dev,
               const int64_t* labels_dev, int64_t* correct_dev);
 
+/* Evaluation tail (a4, every pass of the a5 search): the LAST encoder block followed by the head, computed for
+ * the CLS rows only — keys/values are formed for every token, but the query, the attention output, the
+ * out-projection and the whole MLP run on n rows instead of n*N.  Bit-identical to
+ * ssp2_layers(x, depth-1, depth) + ssp2_head(x) (same per-row instruction sequences); x_dev is NOT modified.
+ * attn_skip_last != 0 bypasses the last block's attention. */
+int ssp2_tail(ssp2_handle h, const float* x_dev, int n, int attn_skip_last, float* logits_dev, int32_t* pred_dev,
+              const int64_t* labels_dev, int64_t* correct_dev);
+
 /* a2 standalone (the hook body on an activation tensor that already sits in HBM):
  *   act_dev bf16 (dtype 0) or f32 (dtype 1), [n, tokens, ld] with the first d columns used;
  *   out_dev f32 [ceil(n/group), out_stride] : out[g][j] = sum_{s in group g} sqrt(sum_t act[s,t,j]^2)

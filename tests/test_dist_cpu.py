@@ -53,6 +53,12 @@ class OracleBackedEngine:
         return lg, lg.argmax(-1), correct
 
     @torch.no_grad()
+    def tail(self, x, n, attn_skip=None, labels=None, correct=None, want_logits=False, want_pred=False):
+        y = x.clone()
+        self.layers(y, n, self.depth - 1, self.depth, attn_skip)
+        return self.head(y, n, labels=labels, correct=correct)
+
+    @torch.no_grad()
     def forward_scores(self, px, site, chain, group=0):
         from oracle import ref_cpu
         group = group if group and group > 0 else px.shape[0]

@@ -306,3 +306,26 @@ def test_eval_chunking_is_exact_and_stage1_packing_is_close(gpu):
     for x, y in zip(c, d):
         ulp = (x.view(torch.int16).int() - y.view(torch.int16).int()).abs()
         assert int(ulp.max()) <= 1
+
+
+@pytest.mark.parametrize("cfg", ["vit_tiny_patch16_224", "vit_test_patch16_32"])
+def test_cls_only_tail_is_bit_identical_to_full_last_block(gpu, cfg):
+    """ssp2_tail (last block + head on the CLS rows only) must reproduce ssp2_layers(L-1, L) + ssp2_head bit for bit,
+    with and without the last block's attention, and must not modify x."""
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights, VIT_CONFIGS
+    w = synthetic_weights(cfg, classes=10, seed=6, std=0.2 if "test" in cfg else 0.05, eps=1e-6, bias_std=0.02)
+    img, depth = VIT_CONFIGS[cfg][0], VIT_CONFIGS[cfg][5]
+    eng = VitEngine(w, max_images=9)
+    g = torch.Generator().manual_seed(2)
+    px = torch.randn(9, 3, img, img, generator=g).to(gpu)
+    labels = torch.randint(0, 10, (9,), generator=g).to(gpu)
+    for skip in (None, [depth - 1], [0, depth - 1]):
+        x = eng.embed(px)
+        eng.layers(x, 9, 0, depth - 1, skip)
+        x_before = x.clone()
+        lt, pt, ct = eng.tail(x, 9, skip, labels=labels, want_logits=True, want_pred=True)
+        assert torch.equal(x, x_before)
+        eng.layers(x, 9, depth - 1, depth, skip)
+        lf, pf, cf = eng.head(x, 9, labels=labels, want_logits=True, want_pred=True)
+        assert torch.equal(lt, lf) and torch.equal(pt, pf) and int(ct) == int(cf)
