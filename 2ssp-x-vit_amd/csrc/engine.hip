@@ -9,12 +9,13 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "attn.hip.h"
-#include "gemm.hip.h"
+#include "gemm256.hip.h"
 #include "misc.hip.h"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -89,6 +90,7 @@ struct ssp2_engine {
   // profiling
   int prof_class = -1;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  double prof_flops = 0;   // algorithmic 2*M*N*K of the recorded GEMM launches
 };
 
 template <typename T>
@@ -106,7 +108,7 @@ static int dalloc(ssp2_engine* e, T** p, size_t count, bool workspace) {
 
 static int mat_alloc(ssp2_engine* e, Mat& m, int rows, int cols) {
   m.rows = rows; m.cols = cols;
-  m.rows_pad = ceil_to(rows, GEMM_BN);
+  m.rows_pad = ceil_to(rows, 256);   // a multiple of both kernels' BN (128 / 256)
   m.ld = ceil_to(cols, GEMM_BK);
   int rc;
   if ((rc = dalloc(e, &m.w, (size_t)m.rows_pad * m.ld, false))) return rc;
@@ -116,8 +118,8 @@ static int mat_alloc(ssp2_engine* e, Mat& m, int rows, int cols) {
 
 struct ProfScope {
   ssp2_engine* e; bool on; hipEvent_t a{}, b{};
-  ProfScope(ssp2_engine* e_, int klass) : e(e_), on(e_->prof_class == klass) {
-    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, e->stream); }
+  ProfScope(ssp2_engine* e_, int klass, double flops = 0) : e(e_), on(e_->prof_class == klass) {
+    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, e->stream); e->prof_flops += flops; }
   }
   ~ProfScope() {
     if (on) { hipEventRecord(b, e->stream); e->prof_events.emplace_back(a, b); }
@@ -125,9 +127,30 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------------ launches
+// Large-M projections go to the 256 x 256 tile kernel (bit-identical results, fewer LDS-DMA issues per MFMA);
+// everything else (small M, fused fc1 epilogue, patch embed, head) stays on the 128 x 128 kernel.
+static const int kBigTileMinRows = 4096;
+template <int EPI>
+static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
+  g.tiles_m = (g.M + 255) / 256;
+  g.tiles_n = (g.N + 255) / 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<256>::LDS));
+    attr_done = true;
+  }
+  ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, 256>), dim3(g.tiles_m * g.tiles_n), dim3(512), G256<256>::LDS, e->stream, g);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 template <int EPI, int SCORE = 0>
 static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
   if (g.K % GEMM_BK) return fail(SSP2_EINVAL, "GEMM K=%d not a multiple of %d", g.K, GEMM_BK);
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID) {
+    if (g.M >= kBigTileMinRows && !getenv("SSP2_NO_BIG_TILES")) return launch_gemm256<EPI>(e, g, klass);
+  }
   g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
   if (g.tiles_m <= 0 || g.tiles_n <= 0) return fail(SSP2_EINVAL, "empty GEMM");
   static bool attr_done = false;
@@ -135,7 +158,7 @@ static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
     HIPCHK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     attr_done = true;
   }
-  ProfScope ps(e, klass);
+  ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SCORE>), dim3(g.tiles_m * g.tiles_n), dim3(256), GEMM_LDS_BYTES, e->stream, g);
   HIPCHK(hipGetLastError());
   return 0;
@@ -526,11 +549,12 @@ int ssp2_profile_begin(ssp2_handle e, int klass) {
   if (!e || klass < 0 || klass >= SSP2_K_COUNT) return fail(SSP2_EINVAL, "bad profile class");
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   e->prof_events.clear();
+  e->prof_flops = 0;
   e->prof_class = klass;
   return 0;
 }
 
-int ssp2_profile_end(ssp2_handle e, double* total_ms, int64_t* launches) {
+int ssp2_profile_end(ssp2_handle e, double* total_ms, int64_t* launches, double* gemm_flops) {
   if (!e) return fail(SSP2_EINVAL, "null handle");
   HIPCHK(hipStreamSynchronize(e->stream));
   double tot = 0;
@@ -542,6 +566,7 @@ int ssp2_profile_end(ssp2_handle e, double* total_ms, int64_t* launches) {
   }
   if (total_ms) *total_ms = tot;
   if (launches) *launches = (int64_t)e->prof_events.size();
+  if (gemm_flops) *gemm_flops = e->prof_flops;
   e->prof_events.clear();
   e->prof_class = -1;
   return 0;

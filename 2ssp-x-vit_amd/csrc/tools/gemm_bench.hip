@@ -6,7 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "../gemm.hip.h"
+#include "../gemm256.hip.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -18,10 +18,17 @@ template <int EPI, int SCORE = 0> static void launch(const GemmArgs& g, hipStrea
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SCORE>), dim3(g.tiles_m * g.tiles_n), dim3(256), GEMM_LDS_BYTES, s, g);
 }
 
+template <int EPI, int BN> static void launch256(GemmArgs g, hipStream_t s) {
+  static bool done = false;
+  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<BN>::LDS)); done = true; }
+  g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, BN>), dim3(g.tiles_m * g.tiles_n), dim3(512), G256<BN>::LDS, s, g);
+}
+
 int main(int argc, char** argv) {
   int M = argc > 1 ? atoi(argv[1]) : 12608, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
   int epi = argc > 4 ? atoi(argv[4]) : 2, iters = argc > 5 ? atoi(argv[5]) : 20, tokens = argc > 6 ? atoi(argv[6]) : 197;
-  int Npad = (N + 127) / 128 * 128;
+  int Npad = (N + 255) / 256 * 256;
   std::vector<uint16_t> hA((size_t)M * K), hW((size_t)Npad * K);
   srand(1);
   for (auto& v : hA) v = f2bf((rand() / (float)RAND_MAX) * 2.f - 1.f);
@@ -43,8 +50,29 @@ int main(int argc, char** argv) {
   hipStream_t s; CK(hipStreamCreate(&s));
   auto run = [&]() {
     switch (epi) { case 0: launch<EPI_BF16>(g, s); break; case 1: launch<EPI_RESID>(g, s); break; case 2: launch<EPI_FC1, 1>(g, s); break; case 5: launch<EPI_FC1, 2>(g, s); break; case 6: launch<EPI_FC1, 0>(g, s); break;
-                   case 3: launch<EPI_PATCH>(g, s); break; default: launch<EPI_F32>(g, s); }
+                   case 3: launch<EPI_PATCH>(g, s); break; case 4: launch<EPI_F32>(g, s); break;
+                   case 10: launch256<EPI_BF16, 256>(g, s); break; case 11: launch256<EPI_RESID, 256>(g, s); break;
+                   case 20: launch256<EPI_BF16, 128>(g, s); break; case 21: launch256<EPI_RESID, 128>(g, s); break; default: break; }
   };
+  if (epi >= 10) {   // verify the large-tile kernel against the (oracle-validated) 128x128 kernel, bit for bit
+    const bool resid = (epi % 10) == 1;
+    size_t xe = (size_t)(M + M / 196 + 2) * Npad, oe = (size_t)M * Npad;
+    CK(hipMemset(x, 0, xe * 4)); CK(hipMemset(out, 0, oe * 2));
+    GemmArgs r = g; r.tiles_m = (M + 127) / 128; r.tiles_n = Npad / 128;
+    if (resid) launch<EPI_RESID>(r, s); else launch<EPI_BF16>(r, s);
+    CK(hipStreamSynchronize(s));
+    std::vector<float> xr(resid ? xe : 0); std::vector<uint16_t> orf(resid ? 0 : oe);
+    if (resid) CK(hipMemcpy(xr.data(), x, xe * 4, hipMemcpyDeviceToHost)); else CK(hipMemcpy(orf.data(), out, oe * 2, hipMemcpyDeviceToHost));
+    CK(hipMemset(x, 0, xe * 4)); CK(hipMemset(out, 0, oe * 2));
+    run(); CK(hipStreamSynchronize(s));
+    size_t bad = 0;
+    if (resid) { std::vector<float> xn(xe); CK(hipMemcpy(xn.data(), x, xe * 4, hipMemcpyDeviceToHost));
+                 for (size_t i = 0; i < (size_t)M * Npad; ++i) { size_t rr = i / Npad, cc = i % Npad; if ((int)cc < N && memcmp(&xn[rr * Npad + cc], &xr[rr * Npad + cc], 4)) ++bad; } }
+    else { std::vector<uint16_t> on(oe); CK(hipMemcpy(on.data(), out, oe * 2, hipMemcpyDeviceToHost));
+           for (size_t i = 0; i < oe; ++i) { if ((int)(i % Npad) < N && on[i] != orf[i]) ++bad; } }
+    printf("verify vs 128x128 kernel: %zu mismatching elements%s\n", bad, bad ? "  <-- FAIL" : " (bit-identical)");
+    CK(hipMemset(x, 0, xe * 4));
+  }
   for (int i = 0; i < 3; ++i) run();
   CK(hipStreamSynchronize(s));
   std::vector<float> ms(iters);

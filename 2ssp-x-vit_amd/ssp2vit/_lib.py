@@ -83,7 +83,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_tail.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     lib.ssp2_act_l2_accum.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, C.c_size_t]
     lib.ssp2_profile_begin.argtypes = [vp, i32]
-    lib.ssp2_profile_end.argtypes = [vp, C.POINTER(C.c_double), i64p]
+    lib.ssp2_profile_end.argtypes = [vp, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double)]
     lib.ssp2_tokens.argtypes = [vp]
     lib.ssp2_workspace_bytes.argtypes = [vp]
     lib.ssp2_workspace_bytes.restype = C.c_size_t

@@ -185,8 +185,8 @@ class VitEngine:
                 return self_inner
 
             def __exit__(self_inner, *exc):
-                ms, cnt = C.c_double(), C.c_int64()
-                check(eng.lib.ssp2_profile_end(eng.h, C.byref(ms), C.byref(cnt)))
-                self_inner.total_ms, self_inner.launches = ms.value, cnt.value
+                ms, cnt, fl = C.c_double(), C.c_int64(), C.c_double()
+                check(eng.lib.ssp2_profile_end(eng.h, C.byref(ms), C.byref(cnt), C.byref(fl)))
+                self_inner.total_ms, self_inner.launches, self_inner.flops = ms.value, cnt.value, fl.value
                 return False
         return _Ctx()

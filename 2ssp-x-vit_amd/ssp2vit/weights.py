@@ -34,6 +34,10 @@ VIT_CONFIGS = {
     "vit_huge_patch14_224": (224, 14, 1280, 16, 5120, 32),
     # the reference's own smoke-test config (experiments/vit_pruning/test_stage2_attention_only.py:44-53)
     "vit_test_patch16_32": (32, 16, 64, 4, 128, 4),
+    # two-block cuts of the large geometries (same kernels / tile shapes as the full models, test-sized)
+    "vit_large_patch16_224_d2": (224, 16, 1024, 16, 4096, 2),
+    "vit_huge_patch14_224_d2": (224, 14, 1280, 16, 5120, 2),
+    "vit_small_patch16_224_d2": (224, 16, 384, 6, 1536, 2),
 }
 
 

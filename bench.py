@@ -189,7 +189,8 @@ def main():
     if rank == 0:
         units_step = args.calib + (depth + 1) * n_eval
         value = world * units_step * args.steps / elapsed
-        executed = args.calib * depth + n_eval * (depth + depth * (depth + 1) // 2)      # block passes per step
+        tail = 2.0 * dim / (4 * dim + 2 * d_int + 2 * tokens)                            # cost of the CLS-only last block / a full block
+        executed = args.calib * depth + n_eval * ((depth - 1) + (depth - 1) * depth // 2 + (depth + 1) * tail)   # block passes per step
         reference_equiv = args.calib * depth + n_eval * depth * (depth + 1)
         line = {
             "metric": "2ssp_prune_image_forwards_per_sec", "value": round(value, 1), "unit": "image-forwards/s",
@@ -207,14 +208,15 @@ def main():
             "selected_blocks": out[3], "pruned_neurons_per_block": plan.per_block_neurons_to_prune,
         }
         if prof is not None and prof.launches:
-            flops = 2.0 * args.batch * tokens * dim * d_int           # algorithmic flops of one fc1 launch
-            avg_ms = prof.total_ms / prof.launches
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel<EPI_FC1> (fc1 + GELU + fused L2 partials)",
+            # dominant kernel family: fc1 (+bias +erf-GELU, + fused activation-L2 partials in stage 1), 128x128 tiles.
+            # achieved = algorithmic flops (2*M*N*K summed over the recorded launches) / summed HIP-event durations.
+            ach = prof.flops / (prof.total_ms * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel<EPI_FC1,*> (fc1 + bias + erf-GELU [+ fused L2 partials])",
                                 "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                                "launches": prof.launches, "avg_launch_us": round(avg_ms * 1e3, 2),
-                                "flops_per_launch": flops}
+                                "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
+                                "flops_per_launch_avg": prof.flops / prof.launches,
+                                "shapes": f"[{args.batch * tokens} | {n_eval * tokens} | {n_eval}] x {d_int} x {dim} (stage-1 batch | search chunk | CLS tail)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, weights)
         print(json.dumps(line), flush=True)

