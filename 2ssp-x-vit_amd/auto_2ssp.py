@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Auto 2SSP for ViT with a single TARGET sparsity — MI355X-native driver with the flag surface of the reference CLI
+(/root/reference/adaptation-for-Pures-framework/auto_2ssp.py:1037-1088) for everything on the prune path.
+
+Flow = reference `run()` (:628-1034): baseline metrics -> plan -> importances (stage-1 activation scores and stage-2
+attention-removal impacts, both on the GPU engine) -> stage-1 width prune -> metrics -> stage-2 attention bypass ->
+metrics -> artifacts (`ffn_prune_masks.json`, `<prefix>_scores.json` / `_masks.json`, `report-<id>.json|.md`).
+
+Out of scope here (network): HF / timm checkpoint and CIFAR loading, fine-tuning, adapters.  Models are seeded
+random-init architectures (`--model vit_base_patch16_224` ...) and data is synthetic ImageNet-shape batches with
+teacher labels; a caller with a real module + dataloader uses `ssp2vit.vit_pruning` directly.
+Extra flags: --sparsity_rate (-2 = the main-table sweep 0.25/0.375/0.5 of main.py:152-157), --seed, --synthetic-*.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+
+import torch  # noqa: E402
+
+from ssp2vit import artifacts, vit_pruning as vp  # noqa: E402
+from ssp2vit.mask_conjunction import Auto2SSPInterface  # noqa: E402
+from ssp2vit.modules import EngineViT  # noqa: E402
+from ssp2vit.weights import VIT_CONFIGS, synthetic_weights  # noqa: E402
+
+
+def measure_latency(model, device, warmup=3, iters=10, img_size=224) -> float:
+    """Reference :196-221 — bs=1 forward, seconds per image."""
+    x = torch.randn(1, 3, img_size, img_size, device=device)
+    for _ in range(warmup):
+        model(x)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(iters):
+        model(x)
+    torch.cuda.synchronize()
+    return (time.time() - t0) / iters
+
+
+def synthetic_loaders(model, img, batch, n_calib, n_eval_batches, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    calib = [{"pixel_values": torch.randn(batch, 3, img, img, generator=g, device=device)} for _ in range(max(1, n_calib // batch))]
+    test = []
+    for _ in range(n_eval_batches):
+        px = torch.randn(batch, 3, img, img, generator=g, device=device)
+        test.append({"pixel_values": px, "labels": model(px).argmax(-1)})      # teacher labels
+    for b in calib:
+        b["labels"] = model(b["pixel_values"]).argmax(-1)
+    return test, calib
+
+
+def run_one(args, target, run_id):
+    device = "cuda"
+    if not torch.cuda.is_available():
+        raise SystemExit("auto_2ssp needs an MI355X: the product path has no CPU fallback")
+    name = args.model if args.model in VIT_CONFIGS else "vit_base_patch16_224"
+    img = VIT_CONFIGS[name][0]
+    model = EngineViT(synthetic_weights(name, classes=args.num_classes, seed=args.seed, std=0.02, spread=4.0))
+    test_loader, cal_loader = synthetic_loaders(model, img, args.batch_size, args.synthetic_calib, max(args.eval_batches, 1),
+                                                args.seed + 1, device)
+    print(f"[INFO] Using device: {device}; model={name}; synthetic calib={len(cal_loader) * args.batch_size} "
+          f"eval={len(test_loader) * args.batch_size} images")
+
+    params_before = vp.count_total_params(model)
+    latency_baseline = measure_latency(model, device, img_size=img)
+    maxb = args.baseline_eval_batches if args.baseline_eval_batches is not None else args.eval_batches
+    acc_baseline = vp.evaluate_top1(model, test_loader, device, max_batches=maxb) if (maxb is None or maxb > 0) else None
+    print(f"[STEP] Baseline computed: params={params_before}, latency_ms={round(latency_baseline * 1000, 2)}, acc={acc_baseline}")
+
+    plan = None
+    if args.stage == "both":
+        plan = vp.plan_2ssp_allocation(model, target, min_remaining=args.min_remaining, forced_blocks=args.force_depth_blocks)
+        print(f"[PLAN] target={plan.target_sparsity:.3f}, blocks_to_prune={plan.blocks_to_prune}, "
+              f"per_block_neurons_to_prune={plan.per_block_neurons_to_prune}")
+    B = len(model.blocks)
+
+    t_prune0 = time.time()
+    imp_mode = "heuristic" if args.stage == "s1" else args.depth_importance
+    iface = Auto2SSPInterface(model, cal_loader, device=device, importance_mode=imp_mode, batch_limit=args.eval_batches,
+                              min_remaining=args.min_remaining, score_chain=args.score_chain)
+    mlp_imp = iface._compute_mlp_importance() if (args.stage in ("both", "s1") and args.s1_importance == "act") else None
+    att_imp = iface._compute_att_depth_importance() if args.stage in ("both", "s2") else None
+
+    ffn_masks = None
+    if args.stage in ("both", "s1"):
+        if args.stage == "both":
+            n_prune = [plan.per_block_neurons_to_prune] * B
+        else:
+            if args.s1_sparsity is None:
+                raise ValueError("When --stage s1, you must provide --s1-sparsity (fraction of FFN params per block to remove).")
+            _, inter = vp._get_hidden_and_inter_sizes(model)
+            n_prune = [max(0, min(int(round(args.s1_sparsity * d)), max(0, d - args.min_remaining))) for d in inter]
+        res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=n_prune, min_remaining=args.min_remaining, strategy="l1",
+                                     collect_masks=True,
+                                     precomputed_importance=[x.to(torch.float32) for x in mlp_imp] if mlp_imp is not None else None)
+        ffn_masks = res["ffn_prune_masks"]
+    params_s1 = vp.count_total_params(model) if args.stage != "s2" else params_before
+    t_s1 = time.time()
+    latency_s1 = measure_latency(model, device, img_size=img)
+    acc_s1 = vp.evaluate_top1(model, test_loader, device, max_batches=args.eval_batches)
+    print(f"[STAGE-1 DONE] params={params_s1}, latency_ms={round(latency_s1 * 1000, 2)}, acc={acc_s1}")
+
+    pruned_indices = []
+    t_s2a = time.time()
+    if args.stage in ("both", "s2"):
+        if args.stage == "both":
+            k = args.force_depth_blocks if args.force_depth_blocks is not None else plan.blocks_to_prune
+            frac = plan.blocks_to_prune / max(1, B)
+        else:
+            if args.s2_sparsity is None:
+                raise ValueError("When --stage s2, you must provide --s2-sparsity (fraction of Attention params / blocks to remove).")
+            k = max(0, min(B - 1, int(round(B * args.s2_sparsity))))
+            frac = k / max(1, B)
+        sel = [int(i) for i in torch.argsort(att_imp)[:k]]                    # reference :857
+        res = vp.prune_vit_attention_blocks(model, sparsity=frac, dataloader=test_loader, device=device,
+                                            batch_limit=args.eval_batches, importance_mode=args.depth_importance,
+                                            show_progress=False, num_to_prune=k, selected_indices=sel)
+        pruned_indices = res["pruned_indices"]
+    t_prune1 = time.time()
+    params_s2 = vp.count_total_params(model)
+    latency_s2 = measure_latency(model, device, img_size=img)
+    acc_s2 = vp.evaluate_top1(model, test_loader, device, max_batches=args.eval_batches)
+    print(f"[STAGE-2 DONE] params={params_s2}, latency_ms={round(latency_s2 * 1000, 2)}, acc={acc_s2}, pruned_blocks={pruned_indices}")
+
+    s1 = vp.compute_actual_sparsity(params_before, params_s1)
+    s2 = vp.compute_actual_sparsity(params_s1, params_s2)
+    st = vp.compute_actual_sparsity(params_before, params_s2)
+    out_root = Path(args.output_dir)
+    art_dir = out_root / "artifacts" / run_id
+    art_dir.mkdir(parents=True, exist_ok=True)
+    arte = {"pruned_block_indices": pruned_indices}
+    if ffn_masks is not None:
+        arte["ffn_prune_masks_path"] = artifacts.save_ffn_prune_masks(str(art_dir / "ffn_prune_masks.json"), ffn_masks)
+    if args.fw_export_prefix:
+        artifacts.build_framework_exports(args.fw_export_prefix, B, model.config.hidden_size, model.config.num_attention_heads,
+                                          mlp_imp, att_imp, ffn_masks, pruned_indices)
+        print(f"[FRAMEWORK] Exported to: {args.fw_export_prefix}_scores.json and {args.fw_export_prefix}_masks.json")
+    if args.save_pruned_model:
+        pdir = Path(args.pruned_output_dir) / run_id
+        pdir.mkdir(parents=True, exist_ok=True)
+        torch.save(model.state_dict(), str(pdir / "timm_model.pth"))                 # reference :881-894 (timm branch)
+        arte["pruned_model_dir"] = str(pdir)
+    pct = lambda a, b: round((a / max(1e-12, b) - 1) * 100, 1)
+    drop = lambda a, b: round(((a - b) / max(1e-12, a)) * 100, 2) if (a is not None and b is not None) else None
+    report = {
+        "config": {"model": name, "target_sparsity": target, "stage": args.stage, "s1_sparsity": args.s1_sparsity,
+                   "s2_sparsity": args.s2_sparsity, "freeze_backbone": False, "replace_classifier": False, "use_adapter": False,
+                   "adapter_reduction": None, "eval_batches": args.eval_batches, "min_remaining": args.min_remaining,
+                   "cifar_load": False, "dataset": "synthetic"},
+        "metrics": {
+            "params_before_stage1": params_before, "params_after_stage1": params_s1, "params_after_stage2": params_s2,
+            "params_before_stage1_millions": round(params_before / 1e6, 2), "params_after_stage1_millions": round(params_s1 / 1e6, 2),
+            "params_after_stage2_millions": round(params_s2 / 1e6, 2),
+            "stage1_reduction_percent": round(s1 * 100, 1), "stage2_reduction_percent": round(s2 * 100, 1),
+            "total_reduction_percent": round(st * 100, 1),
+            "latency_baseline_ms": round(latency_baseline * 1000, 2), "latency_stage1_ms": round(latency_s1 * 1000, 2),
+            "latency_stage2_ms": round(latency_s2 * 1000, 2), "latency_stage1_change_percent": pct(latency_s1, latency_baseline),
+            "latency_stage2_change_percent": pct(latency_s2, latency_s1), "latency_total_change_percent": pct(latency_s2, latency_baseline),
+            "acc_baseline": round(acc_baseline, 4) if acc_baseline is not None else None,
+            "acc_stage1": round(acc_s1, 4), "acc_stage2": round(acc_s2, 4),
+            "acc_drop_stage1_percent": drop(acc_baseline, acc_s1), "acc_drop_stage2_percent": drop(acc_s1, acc_s2),
+            "acc_total_drop_percent": drop(acc_baseline, acc_s2),
+            # additions of this build: the prune-time bracket of main.py:164-198 (importance .. stage-2 apply)
+            "prune_time_s": round((t_s1 - t_prune0) + (t_prune1 - t_s2a), 4),
+        },
+        "artifacts": arte,
+    }
+    if plan is not None:
+        report["plan"] = dict(plan.__dict__)
+    saved = vp.save_report(report, str(out_root / "reports"), run_id=run_id)
+    print("[SUMMARY]")
+    print(json.dumps(report["metrics"], indent=2))
+    print(f"[INFO] Report saved to: {saved['json']} and {saved['md']}")
+    vp.release_engines()
+    return report
+
+
+def build_argparser():
+    p = argparse.ArgumentParser(description="Auto 2SSP for ViT with single TARGET sparsity (MI355X-native engine).")
+    p.add_argument("--model", type=str, default="vit_base_patch16_224", help=f"architecture: one of {sorted(VIT_CONFIGS)}")
+    p.add_argument("--target", type=float, required=False)
+    p.add_argument("--sparsity_rate", type=float, default=None, help="alias of --target; -2 sweeps 0.25/0.375/0.5")
+    p.add_argument("--stage", type=str, default="both", choices=["both", "s1", "s2"])
+    p.add_argument("--s1-sparsity", type=float, default=None)
+    p.add_argument("--s2-sparsity", type=float, default=None)
+    p.add_argument("--min-remaining", type=int, default=512)
+    p.add_argument("--eval-batches", type=int, default=5)
+    p.add_argument("--baseline-eval-batches", type=int, default=None)
+    p.add_argument("--s1-importance", type=str, default="act", choices=["act", "l1"])
+    p.add_argument("--depth-importance", type=str, default="copy", choices=["copy", "heuristic"])
+    p.add_argument("--force-depth-blocks", type=int, default=None)
+    p.add_argument("--force-copy-eval", action="store_true", help="accepted for compatibility (no MPS here)")
+    p.add_argument("--save-pruned-model", action="store_true")
+    p.add_argument("--pruned-output-dir", type=str, default=str(HERE / "pruned_models"))
+    p.add_argument("--fw-export-prefix", type=str, default=None)
+    p.add_argument("--output-dir", type=str, default=str(HERE / "runs"), help="reports/ and artifacts/ are created below it")
+    # synthetic stand-ins for the network-loaded model/data of the reference
+    p.add_argument("--num-classes", type=int, default=1000)
+    p.add_argument("--batch-size", type=int, default=64)
+    p.add_argument("--synthetic-calib", type=int, default=512)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--score-chain", type=str, default="fp32", choices=["fp32", "bf16_ref"])
+    # accepted and ignored (data / fine-tuning flags of the reference that need the network)
+    for flag in ("--load-cifar", "--do-finetune", "--freeze-backbone", "--replace-classifier", "--use-adapter", "--save-adapter",
+                 "--use-srp-checkpoint"):
+        p.add_argument(flag, action="store_true", help=argparse.SUPPRESS)
+    for flag in ("--dataset", "--load-adapter", "--srp-model-type", "--srp-dataset", "--srp-index-csv", "--srp-models-dir",
+                 "--srp-checkpoint-npz"):
+        p.add_argument(flag, type=str, default=None, help=argparse.SUPPRESS)
+    for flag, typ in (("--calib-per-class", int), ("--cifar-train-pct", float), ("--cifar-test-pct", float), ("--ft-epochs", int),
+                      ("--ft-lr", float), ("--adapter-reduction", int), ("--srp-res", int)):
+        p.add_argument(flag, type=typ, default=None, help=argparse.SUPPRESS)
+    return p
+
+
+def main(argv=None):
+    args = build_argparser().parse_args(argv)
+    rate = args.sparsity_rate if args.sparsity_rate is not None else args.target
+    targets = [0.25, 0.375, 0.5] if rate == -2 else [rate]
+    if args.stage == "both" and any(t is None for t in targets):
+        raise SystemExit("--target (or --sparsity_rate) is required when --stage both")
+    stamp = time.strftime("%Y%m%d-%H%M%S")
+    return [run_one(args, t, f"{stamp}-s{t}" if len(targets) > 1 else stamp) for t in targets]
+
+
+if __name__ == "__main__":
+    main()

@@ -212,9 +212,61 @@ def heuristic_and_exports():
     print("[golden] framework_export.json written")
 
 
+def artifact_tool_cases():
+    """Score/mask JSON tooling: run the reference's stdlib-only scripts on small random leaves."""
+    import importlib.util
+    import random
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    me = os.path.join(REF, "manual-experiments")
+    norm = load(os.path.join(me, "normalize_scores.py"), "ref_normalize")
+    agg = load(os.path.join(me, "aggregate_and_mask-summation.py"), "ref_aggregate")
+    cons = load(os.path.join(me, "consensus_mask.py"), "ref_consensus")
+    rnd = random.Random(5)
+    files = []
+    for f in range(3):
+        leaf = {}
+        for b in range(3):
+            for j in range(20 if b < 2 else 17):                     # ragged last block
+                leaf[f"{b}:{j}"] = round(rnd.random() * (f + 1), 3) if rnd.random() > 0.15 else 0.5   # ties
+        files.append(leaf)
+    out = {"files": files, "cases": []}
+    tree = {"ffn": files[0], "meta": {"name": "x", "vals": [1, 2.5, True, None]}}
+    lo, hi = norm.scan_min_max_raw(tree)
+    out["normalize"] = {"input": tree, "output": norm.normalize_structure(tree, lo, hi)}
+    out["normalize_const"] = {"input": {"a": [2, 2]}, "output": norm.normalize_structure({"a": [2, 2]}, 2.0, 2.0)}
+    summed = {}
+    for leaf in files:
+        for k, v in leaf.items():
+            summed[k] = summed.get(k, 0.0) + v
+    for frac, rounding, pbk in ((0.25, "round", None), (0.5, "floor", None), (0.3, "ceil", None), (0.3, "round", 4), (0.0, "round", None)):
+        m = quiet(agg.make_mask_for_leaf, summed, frac, rounding, pbk)
+        out["cases"].append({"kind": "bottom_k", "fraction": frac, "rounding": rounding, "per_block_k": pbk, "mask": m})
+    for frac, rounding in ((0.25, "round"), (0.4, "floor"), (0.1, "ceil")):
+        m = quiet(cons.consensus_for_path, files, frac, rounding, False)
+        out["cases"].append({"kind": "consensus", "fraction": frac, "rounding": rounding, "mask": m})
+    try:
+        amp = load(os.path.join(REF, "experiments", "vit_pruning", "apply_mask_prune.py"), "ref_apply_mask")
+        print("[golden] apply_mask_prune imported")
+    except Exception as e:
+        print("[golden] apply_mask_prune import failed (ordinary error; load_mask restated from source only):", repr(e)[:120])
+    with open(os.path.join(HERE, "artifact_tools.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("[golden] artifact_tools.json written:", len(out["cases"]), "cases")
+
+
 if __name__ == "__main__":
+    if "--artifacts-only" in sys.argv:
+        artifact_tool_cases()
+        sys.exit(0)
     tiny_case("timm", std=0.25)
     tiny_case("hf", std=0.25)
     vit_tiny_case()
     planner_cases()
     heuristic_and_exports()
+    artifact_tool_cases()

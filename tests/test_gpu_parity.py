@@ -358,3 +358,36 @@ def test_other_geometries_vs_oracle(gpu, cfg, layout):
     m2 = copy.deepcopy(model); ref_cpu.bypass_attention_(m2, 1)
     r2 = ref_cpu.logits_of(m2, px).float()
     assert (skip - r2).abs().max() <= _logit_tol(r2)
+
+
+def test_cli_end_to_end_on_synthetic_vit_tiny(gpu, tmp_path):
+    """auto_2ssp-compatible driver: plan -> importances -> stage 1 -> stage 2 -> artifacts/report with the reference's
+    file names and metric keys (auto_2ssp.py:981-1023)."""
+    import importlib.util
+    import json
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("auto_2ssp_amd", os.path.join(PKG, "auto_2ssp.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    out = tmp_path / "run"
+    rep = cli.main(["--model", "vit_tiny_patch16_224", "--target", "0.3", "--eval-batches", "2", "--batch-size", "16",
+                    "--synthetic-calib", "32", "--num-classes", "10", "--min-remaining", "256", "--output-dir", str(out),
+                    "--fw-export-prefix", str(out / "fw"), "--save-pruned-model", "--pruned-output-dir", str(out / "pm")])[0]
+    m = rep["metrics"]
+    ref_keys = {"params_before_stage1", "params_after_stage1", "params_after_stage2", "params_before_stage1_millions",
+                "params_after_stage1_millions", "params_after_stage2_millions", "stage1_reduction_percent",
+                "stage2_reduction_percent", "total_reduction_percent", "latency_baseline_ms", "latency_stage1_ms",
+                "latency_stage2_ms", "latency_stage1_change_percent", "latency_stage2_change_percent",
+                "latency_total_change_percent", "acc_baseline", "acc_stage1", "acc_stage2", "acc_drop_stage1_percent",
+                "acc_drop_stage2_percent", "acc_total_drop_percent"}
+    assert ref_keys <= set(m)
+    assert m["acc_baseline"] == 1.0                                   # teacher labels
+    plan = rep["plan"]
+    assert len(rep["artifacts"]["pruned_block_indices"]) == plan["blocks_to_prune"]
+    masks = json.load(open(rep["artifacts"]["ffn_prune_masks_path"]))["ffn_masks"]
+    assert len(masks) == 12 and all(sum(r) == plan["per_block_neurons_to_prune"] and len(r) == 768 for r in masks)
+    removed = (m["params_before_stage1"] - m["params_after_stage2"]) / m["params_before_stage1"]
+    assert abs(removed - 0.3) < 0.02
+    fw = json.load(open(str(out / "fw") + "_masks.json"))
+    assert set(fw) == {"ffn", "heads", "qkv_dim"} and len(fw["ffn"]) == 12
+    assert os.path.exists(os.path.join(rep["artifacts"]["pruned_model_dir"], "timm_model.pth"))
+    assert any(f.startswith("report-") and f.endswith(".md") for f in os.listdir(out / "reports"))
