@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -71,6 +72,7 @@ struct ssp2_engine {
   int tokens = 0, patches = 0, side = 0, dh = 0;
   int kpe = 0, kpe_pad = 0, ld_int_max = 0;
   hipStream_t stream = nullptr;
+  int n_cu = 256;
   std::vector<void*> allocs;
   size_t ws_bytes = 0, weight_bytes = 0;
 
@@ -140,7 +142,7 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
     attr_done = true;
   }
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
-  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, 256>), dim3(g.tiles_m * g.tiles_n), dim3(512), G256<256>::LDS, e->stream, g);
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, 256>), dim3(std::min(g.tiles_m * g.tiles_n, e->n_cu)), dim3(512), G256<256>::LDS, e->stream, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -233,6 +235,10 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
 
   auto* e = new ssp2_engine();
   e->d = d;
+  {
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) e->n_cu = pr.multiProcessorCount;
+  }
   e->d_int.assign(d.d_int, d.d_int + d.depth);
   e->d.d_int = e->d_int.data();
   e->side = d.img / d.patch;

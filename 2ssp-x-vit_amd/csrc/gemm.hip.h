@@ -111,6 +111,12 @@ __device__ __forceinline__ void wave_store_bf16_tile(const char* stg, bf16* out,
   }
 }
 
+#ifdef GEMM_STAMPS
+#define STAMP(slot) do { if (tid == 0 && (slot) < 64) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g.stamps[(size_t)blockIdx.x * 64 + (slot)] = t_; } } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 template <int EPI, int SCORE = 0>   // SCORE (EPI_FC1 only): 0 none, 1 pre-GELU, 2 post-GELU
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,11 +198,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
   int sa = 0, sb = 0;          // ring slots of tile kt
 #ifdef ABL_NO_LDSREAD
   bf16x8 abl_a[4][2], abl_b[4][2];
-#endif
-#ifdef GEMM_STAMPS
-#define STAMP(slot) do { if (tid == 0 && (slot) < 64) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g.stamps[(size_t)blockIdx.x * 64 + (slot)] = t_; } } while (0)
-#else
-#define STAMP(slot) do {} while (0)
 #endif
   STAMP(0);
   for (int kt = 0; kt < nk; ++kt) {

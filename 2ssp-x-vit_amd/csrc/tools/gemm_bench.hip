@@ -18,14 +18,16 @@ template <int EPI, int SCORE = 0> static void launch(const GemmArgs& g, hipStrea
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SCORE>), dim3(g.tiles_m * g.tiles_n), dim3(256), GEMM_LDS_BYTES, s, g);
 }
 
+static int nCU = 256;
 template <int EPI, int BN> static void launch256(GemmArgs g, hipStream_t s) {
   static bool done = false;
   if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<BN>::LDS)); done = true; }
   g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, BN>), dim3(g.tiles_m * g.tiles_n), dim3(512), G256<BN>::LDS, s, g);
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, BN>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(512), G256<BN>::LDS, s, g);
 }
 
 int main(int argc, char** argv) {
+  { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); nCU = pr.multiProcessorCount; }
   int M = argc > 1 ? atoi(argv[1]) : 12608, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
   int epi = argc > 4 ? atoi(argv[4]) : 2, iters = argc > 5 ? atoi(argv[5]) : 20, tokens = argc > 6 ? atoi(argv[6]) : 197;
   int Npad = (N + 255) / 256 * 256;
@@ -52,7 +54,7 @@ int main(int argc, char** argv) {
     switch (epi) { case 0: launch<EPI_BF16>(g, s); break; case 1: launch<EPI_RESID>(g, s); break; case 2: launch<EPI_FC1, 1>(g, s); break; case 5: launch<EPI_FC1, 2>(g, s); break; case 6: launch<EPI_FC1, 0>(g, s); break;
                    case 3: launch<EPI_PATCH>(g, s); break; case 4: launch<EPI_F32>(g, s); break;
                    case 10: launch256<EPI_BF16, 256>(g, s); break; case 11: launch256<EPI_RESID, 256>(g, s); break;
-                   case 20: launch256<EPI_BF16, 128>(g, s); break; case 21: launch256<EPI_RESID, 128>(g, s); break; default: break; }
+                   default: break; }
   };
   if (epi >= 10) {   // verify the large-tile kernel against the (oracle-validated) 128x128 kernel, bit for bit
     const bool resid = (epi % 10) == 1;
@@ -101,6 +103,13 @@ int main(int argc, char** argv) {
     }
     printf("stamps (cycles, wave 0 of every block): per-iteration issue+mfma %.0f  vmcnt-wait %.0f  barrier %.0f ; main loop per block %.0f ; kernel span %.0f\n",
            mfma / cnt, wait / cnt, bar / cnt, tot / nb, (double)(tmax - tmin));
+    if (epi >= 10) {   // persistent kernel: per-workgroup totals
+      int G = std::min(((M + 255) / 256) * ((N + 255) / 256), nCU);
+      double cyc = 0, rt = 0, tl = 0, loop1 = 0;
+      for (int b = 0; b < G; ++b) { const unsigned long long* t = &h[(size_t)b * 64]; cyc += (double)(t[59] - t[0]); rt += (double)(t[62] - t[61]); tl += (double)t[63]; loop1 += (double)(t[60] - t[0]); }
+      printf("persistent: %d workgroups, avg tiles/wg %.2f, avg lifetime %.0f cycles = %.1f us (s_memrealtime, 100 MHz) -> clock %.2f GHz ; cycles per tile %.0f ; last tile main loop %.0f\n",
+             G, tl / G, cyc / G, rt / G / 100.0, (cyc / G) / (rt / G / 100.0) / 1e3, cyc / tl, loop1 / G);
+    }
     // distribution of block start times (first 16 and a few later)
     for (int b : {0, 1, 255, 256, 511, 512, 513, 1000, 2000}) if (b < nb) printf("  block %d start %+lld loop %lld\n", b, (long long)(h[(size_t)b * 64] - tmin), (long long)(h[(size_t)b * 64 + 60] - h[(size_t)b * 64]));
   }
