@@ -64,6 +64,7 @@ struct Layer {
   bool ln_set[4] = {false, false, false, false};
   Mat qkv, proj, fc1, fc2;
   int d_int = 0, ld_int = 0;
+  bool attn_dropped = false;   // ssp2_drop_attention: bypass for good
 };
 
 struct ssp2_engine {
@@ -412,7 +413,7 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
   const bool fused = score_site && e->tokens >= GEMM_BM;   // a 128-row tile then spans at most two samples
   for (int l = l_begin; l < l_end; ++l) {
     Layer& L = e->layers[l];
-    const bool skip = attn_skip && attn_skip[l];
+    const bool skip = L.attn_dropped || (attn_skip && attn_skip[l]);
     if (!(L.ln_set[2] && L.ln_set[3] && L.fc1.w_set && L.fc1.b_set && L.fc2.w_set && L.fc2.b_set))
       return fail(SSP2_ESTATE, "layer %d MLP weights not loaded", l);
     if (!skip) {
@@ -501,7 +502,7 @@ int ssp2_tail(ssp2_handle e, const float* x, int n, int attn_skip_last, float* l
   if (!(L.ln_set[2] && L.ln_set[3] && L.fc1.w_set && L.fc1.b_set && L.fc2.w_set && L.fc2.b_set)) return fail(SSP2_ESTATE, "last layer MLP weights not loaded");
   // x_cls <- CLS rows of x (x itself is left untouched)
   HIPCHK(hipMemcpy2DAsync(e->x_cls, (size_t)D * 4, x, (size_t)e->tokens * D * 4, (size_t)D * 4, n, hipMemcpyDeviceToDevice, e->stream));
-  if (!attn_skip_last) {
+  if (!attn_skip_last && !L.attn_dropped) {
     if (!(L.ln_set[0] && L.ln_set[1] && L.qkv.w_set && L.qkv.b_set && L.proj.w_set && L.proj.b_set)) return fail(SSP2_ESTATE, "last layer attention weights not loaded");
     // keys / values need every token; the query, the out-projection and the MLP only the CLS row
     if ((rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, e->hbuf, D, M, D))) return rc;
@@ -530,6 +531,50 @@ int ssp2_tail(ssp2_handle e, const float* x, int n, int attn_skip_last, float* l
   o.M = n; o.N = D; o.K = L.ld_int; o.tiles_n = L.fc2.rows_pad / GEMM_BN; o.x = e->x_cls; o.ldx = D;
   if ((rc = launch_gemm<EPI_RESID>(e, o, SSP2_K_GEMM_FC2))) return rc;
   return head_impl(e, e->x_cls, (size_t)D, n, logits_dev, pred, labels, correct);
+}
+
+int ssp2_d_int(ssp2_handle e, int layer) {
+  if (!e || layer < 0 || layer >= e->d.depth) return fail(SSP2_EINVAL, "bad layer");
+  return e->layers[layer].d_int;
+}
+
+int ssp2_drop_attention(ssp2_handle e, int layer) {
+  if (!e || layer < 0 || layer >= e->d.depth) return fail(SSP2_EINVAL, "bad layer");
+  e->layers[layer].attn_dropped = true;
+  return 0;
+}
+
+int ssp2_prune_ffn(ssp2_handle e, int layer, const int32_t* keep, int n_keep) {
+  if (!e || !keep || layer < 0 || layer >= e->d.depth) return fail(SSP2_EINVAL, "bad argument");
+  Layer& L = e->layers[layer];
+  if (n_keep <= 0 || n_keep > L.d_int) return fail(SSP2_EINVAL, "n_keep=%d outside (0, d_int=%d]", n_keep, L.d_int);
+  for (int i = 0; i < n_keep; ++i)
+    if (keep[i] < 0 || keep[i] >= L.d_int || (i && keep[i] <= keep[i - 1])) return fail(SSP2_EINVAL, "keep list must be ascending and inside [0, d_int)");
+  if (!(L.fc1.w_set && L.fc1.b_set && L.fc2.w_set)) return fail(SSP2_ESTATE, "layer %d MLP weights not loaded", layer);
+  const int D = e->d.dim;
+  const int new_ld = ceil_to(n_keep, GEMM_BK);
+  int* keep_dev = nullptr;
+  bf16 *t1 = nullptr, *t2 = nullptr;
+  float* tb = nullptr;
+  const size_t fc1_elems = (size_t)L.fc1.rows_pad * L.fc1.ld, fc2_elems = (size_t)L.fc2.rows_pad * new_ld;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMalloc(&keep_dev, (size_t)n_keep * 4));
+  HIPCHK(hipMalloc(&t1, fc1_elems * 2)); HIPCHK(hipMalloc(&t2, fc2_elems * 2)); HIPCHK(hipMalloc(&tb, (size_t)L.fc1.rows_pad * 4));
+  HIPCHK(hipMemcpy(keep_dev, keep, (size_t)n_keep * 4, hipMemcpyHostToDevice));
+  // fc1: rows gathered, same leading dimension (K = dim); fc2: columns gathered into the new, smaller leading dimension
+  hipLaunchKernelGGL(gather_matrix_kernel, dim3(2048), dim3(256), 0, e->stream, L.fc1.w, L.fc1.ld, t1, L.fc1.ld, L.fc1.rows_pad, n_keep, D, keep_dev, (const int*)nullptr);
+  hipLaunchKernelGGL(gather_vector_kernel, dim3((L.fc1.rows_pad + 255) / 256), dim3(256), 0, e->stream, L.fc1.b, tb, L.fc1.rows_pad, n_keep, keep_dev);
+  hipLaunchKernelGGL(gather_matrix_kernel, dim3(2048), dim3(256), 0, e->stream, L.fc2.w, L.fc2.ld, t2, new_ld, L.fc2.rows_pad, D, n_keep, (const int*)nullptr, keep_dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(L.fc1.w, t1, fc1_elems * 2, hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(L.fc1.b, tb, (size_t)L.fc1.rows_pad * 4, hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(L.fc2.w, t2, fc2_elems * 2, hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  hipFree(keep_dev); hipFree(t1); hipFree(t2); hipFree(tb);
+  L.d_int = n_keep; L.ld_int = new_ld;
+  L.fc1.rows = n_keep; L.fc2.cols = n_keep; L.fc2.ld = new_ld;
+  e->d_int[layer] = n_keep;
+  return 0;
 }
 
 int ssp2_act_l2_accum(void* stream, const void* act, int dtype, int n, int tokens, int d, int ld, int chain, int group,

@@ -216,3 +216,22 @@ __global__ __launch_bounds__(256) void argmax_top1_kernel(const float* __restric
     if (labels && correct && labels[row] == (int64_t)bi) atomicAdd(correct, 1ULL);
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight compaction for the width prune (a8): dst[r][c] = src[map_r(r)][map_c(c)] over bf16 matrices, zero padding.
+//   rows_keep != nullptr : row r of dst comes from row rows_keep[r] of src (fc1: neurons are rows)
+//   cols_keep != nullptr : col c of dst comes from col cols_keep[c] of src (fc2: neurons are columns)
+__global__ void gather_matrix_kernel(const bf16* __restrict__ src, int src_ld, bf16* __restrict__ dst, int dst_ld, int dst_rows_pad,
+                                     int n_rows, int n_cols, const int* __restrict__ rows_keep, const int* __restrict__ cols_keep) {
+  const long total = (long)dst_rows_pad * dst_ld;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / dst_ld), c = (int)(i - (long)r * dst_ld);
+    bf16 v = (bf16)0.f;
+    if (r < n_rows && c < n_cols) v = src[(size_t)(rows_keep ? rows_keep[r] : r) * src_ld + (cols_keep ? cols_keep[c] : c)];
+    dst[i] = v;
+  }
+}
+__global__ void gather_vector_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_pad, int n, const int* __restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) dst[i] = i < n ? src[keep[i]] : 0.f;
+}

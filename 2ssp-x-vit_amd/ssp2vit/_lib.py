@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 # every symbol include/ssp2vit.h declares
 SYMBOLS = [
     "ssp2_abi_version", "ssp2_last_error", "ssp2_create", "ssp2_destroy", "ssp2_set_stream", "ssp2_load_tensor",
-    "ssp2_embed", "ssp2_layers", "ssp2_head", "ssp2_tail", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
+    "ssp2_embed", "ssp2_layers", "ssp2_head", "ssp2_tail", "ssp2_prune_ffn", "ssp2_drop_attention", "ssp2_d_int", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
     "ssp2_tokens", "ssp2_workspace_bytes",
 ]
 
@@ -81,6 +81,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_layers.argtypes = [vp, vp, i32, i32, i32, C.POINTER(C.c_uint8), i32, i32, i32, vp, i32]
     lib.ssp2_head.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     lib.ssp2_tail.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.ssp2_prune_ffn.argtypes = [vp, i32, C.POINTER(C.c_int32), i32]
+    lib.ssp2_drop_attention.argtypes = [vp, i32]
+    lib.ssp2_d_int.argtypes = [vp, i32]
     lib.ssp2_act_l2_accum.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, C.c_size_t]
     lib.ssp2_profile_begin.argtypes = [vp, i32]
     lib.ssp2_profile_end.argtypes = [vp, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double)]

@@ -68,6 +68,27 @@ class VitEngine:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ applying a prune on the device (f2)
+    def prune_ffn(self, layer: int, keep: Sequence[int]) -> None:
+        """Keep only the FFN neurons `keep` (ascending) of block `layer`: fc1 rows / bias and fc2 columns are gathered
+        in HBM (reference src/vit_pruning.py:297-311 on the module).  No re-upload of weights."""
+        arr = (C.c_int32 * len(keep))(*[int(k) for k in keep])
+        with torch.cuda.device(self.device):
+            check(self.lib.ssp2_prune_ffn(self.h, int(layer), arr, len(keep)))
+        self.d_int[layer] = len(keep)
+
+    def apply_ffn_masks(self, masks: Sequence[Sequence[int]]) -> None:
+        """masks[l][j] == 1 -> prune neuron j of block l (the `ffn_prune_masks` of prune_vit_mlp_width)."""
+        for l, m in enumerate(masks):
+            keep = [j for j, bit in enumerate(m) if not bit]
+            if len(keep) != self.d_int[l]:
+                self.prune_ffn(l, keep)
+
+    def drop_attention(self, layers: Sequence[int]) -> None:
+        for l in layers:
+            check(self.lib.ssp2_drop_attention(self.h, int(l)))
+            self.absent[int(l)] = True
+
     # ------------------------------------------------------------------ plumbing
     def _bind_stream(self) -> None:
         check(self.lib.ssp2_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))

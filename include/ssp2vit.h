@@ -107,6 +107,15 @@ int ssp2_head(ssp2_handle h, const float* x_dev, int n, float* logits_dev, int32
 int ssp2_tail(ssp2_handle h, const float* x_dev, int n, int attn_skip_last, float* logits_dev, int32_t* pred_dev,
               const int64_t* labels_dev, int64_t* correct_dev);
 
+/* a8 on the device: keep only the listed FFN neurons of block `layer` — rows of fc1 (+bias) and
+ * columns of fc2 are gathered in HBM (src/vit_pruning.py:297-311 does `W_int[keep]`, `B_int[keep]`, `W_out[:,keep]`
+ * on the module); keep_host is ascending, 0 < n_keep <= current d_int.  The engine then runs with the smaller
+ * d_int exactly as an engine created from the sliced weights would (bit-identical).  Synchronous. */
+int ssp2_prune_ffn(ssp2_handle h, int layer, const int32_t* keep_host, int n_keep);
+/* a6/a9 applied for good: block `layer` loses its attention sub-module (always bypassed from now on). */
+int ssp2_drop_attention(ssp2_handle h, int layer);
+int ssp2_d_int(ssp2_handle h, int layer);
+
 /* a2 standalone (the hook body on an activation tensor that already sits in HBM):
  *   act_dev bf16 (dtype 0) or f32 (dtype 1), [n, tokens, ld] with the first d columns used;
  *   out_dev f32 [ceil(n/group), out_stride] : out[g][j] = sum_{s in group g} sqrt(sum_t act[s,t,j]^2)

@@ -391,3 +391,31 @@ def test_cli_end_to_end_on_synthetic_vit_tiny(gpu, tmp_path):
     assert set(fw) == {"ffn", "heads", "qkv_dim"} and len(fw["ffn"]) == 12
     assert os.path.exists(os.path.join(rep["artifacts"]["pruned_model_dir"], "timm_model.pth"))
     assert any(f.startswith("report-") and f.endswith(".md") for f in os.listdir(out / "reports"))
+
+
+def test_on_device_compaction_equals_engine_from_sliced_weights(gpu):
+    """f2: ssp2_prune_ffn / ssp2_drop_attention on a live engine == a fresh engine built from the host-sliced module
+    (reference weight surgery, src/vit_pruning.py:297-311, :499-504): bit-identical logits and scores."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp, weights as W
+    from ssp2vit.engine import VitEngine
+    w = W.synthetic_weights("vit_tiny_patch16_224", classes=10, seed=3, std=0.05, eps=1e-6, bias_std=0.02)
+    g = torch.Generator().manual_seed(12)
+    px = torch.randn(5, 3, 224, 224, generator=g).to(gpu)
+    eng = VitEngine(w, max_images=5)
+    imps = [eng.forward_scores(px, "pre_gelu")[0][l, :768].cpu() for l in range(12)]
+    model = build_from_flat(w, "timm")                                   # host module, used only for the surgery
+    res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[100 + 7 * l for l in range(12)], min_remaining=256,
+                                 collect_masks=True, precomputed_importance=imps)
+    vp._apply_bypass(model, 3); vp._apply_bypass(model, 11)
+    eng.apply_ffn_masks(res["ffn_prune_masks"])
+    eng.drop_attention([3, 11])
+    assert eng.d_int == [768 - 100 - 7 * l for l in range(12)]
+    fresh = VitEngine(W.from_module(model), max_images=5)
+    assert torch.equal(eng.forward_logits(px), fresh.forward_logits(px))
+    a, b = eng.forward_scores(px, "post_gelu")[0], fresh.forward_scores(px, "post_gelu")[0]
+    for l, d in enumerate(eng.d_int):                                    # (score rows are padded to each engine's own ld)
+        assert torch.equal(a[l, :d], b[l, :d])
+    from ssp2vit._lib import Ssp2Error
+    with pytest.raises(Ssp2Error):
+        eng.prune_ffn(0, [5, 4])                                         # not ascending
