@@ -419,3 +419,26 @@ def test_on_device_compaction_equals_engine_from_sliced_weights(gpu):
     from ssp2vit._lib import Ssp2Error
     with pytest.raises(Ssp2Error):
         eng.prune_ffn(0, [5, 4])                                         # not ascending
+
+
+def test_iterative_depth_search_matches_brute_force_and_oracle(gpu):
+    """BASELINE configs[3] semantics (greedy K-round search of src/utilities.py:446-505 with top-1 as the metric):
+    the prefix-cached GPU search must pick exactly what a brute-force loop over full engine evaluations picks, and
+    the per-round accuracies must agree with the CPU oracle's greedy search within 1 image of 16."""
+    from oracle import ref_cpu
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    w, batches, _ = load_tiny_golden("timm")
+    model = build_from_flat(w, "timm")
+    removed = []
+    for _ in range(2):                                                     # brute force on the engine
+        rest = [i for i in range(4) if i not in removed]
+        acc = {i: vp._top1_counts(model, batches, "cuda", 5, attn_skip=removed + [i])[0] for i in rest}
+        removed.append(max(rest, key=lambda i: (acc[i], -i)))
+    res = vp.prune_vit_attention_blocks(build_from_flat(w, "timm"), sparsity=0.5, dataloader=batches, device="cuda",
+                                        batch_limit=5, show_progress=False, num_to_prune=2, search="iterative")
+    assert res["pruned_indices"] == sorted(removed)
+    o_removed, trace = ref_cpu.greedy_depth_search(model, batches, 2, 5)
+    g_first = vp._top1_counts(model, batches, "cuda", 5, attn_skip=[o_removed[0]])[0] / 16
+    assert abs(g_first - trace[0][1]) <= 1 / 16 + 1e-9
+    vp.release_engines()
