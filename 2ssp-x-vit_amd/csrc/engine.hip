@@ -139,11 +139,11 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
   g.tiles_n = (g.N + 255) / 256;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<256>::LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<8>::LDS));
     attr_done = true;
   }
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
-  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, 256>), dim3(std::min(g.tiles_m * g.tiles_n, e->n_cu)), dim3(512), G256<256>::LDS, e->stream, g);
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, 8>), dim3(std::min(g.tiles_m * g.tiles_n, e->n_cu)), dim3(512), G256<8>::LDS, e->stream, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -435,6 +435,7 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
     f.A = e->hbuf; f.lda = D; f.W = L.fc1.w; f.ldw = L.fc1.ld; f.bias = L.fc1.b;
     f.M = M; f.N = L.ld_int; f.K = D; f.tiles_n = L.fc1.rows_pad / GEMM_BN; f.out = e->actbuf; f.ldo = L.ld_int;
     f.score_site = fused ? score_site : 0; f.tokens = e->tokens; f.slab = e->slab; f.slab_ld = L.ld_int;
+    f.group_m = 8;   // 8 x 8 tile patches per XCD: the 4.7 MB fc1 weight no longer thrashes the 4 MiB L2 (PMC: FETCH_SIZE / 3.7)
     // unfused pre-GELU scoring (models with < 128 tokens): the hook sees fc1's output, fc2 consumes the GELU
     // of it, so the epilogue also stores the pre-activation for the standalone L2 kernel to read.
     f.out2 = (score_site == SSP2_SCORE_PRE_GELU && !fused) ? e->prebuf : nullptr;

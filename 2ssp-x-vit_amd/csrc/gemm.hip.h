@@ -196,34 +196,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
   int sa = 0, sb = 0;          // ring slots of tile kt
-#ifdef ABL_NO_LDSREAD
-  bf16x8 abl_a[4][2], abl_b[4][2];
-#endif
   STAMP(0);
   for (int kt = 0; kt < nk; ++kt) {
     const int sa2 = sa >= 1 ? sa - 1 : 2;          // (kt+2) % 3
-#ifndef ABL_NO_GLDS
     if (kt + 1 < nk) stage_b(sb ^ 1, kt + 1);
     if (kt + 2 < nk) stage_a(sa2, kt + 2);
-#endif
     const char* As = smA + sa * GEMM_STAGE_BYTES;
     const char* Bs = smB + sb * GEMM_STAGE_BYTES;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int chunk = 2 * s + lh;
       bf16x8 fa[2], fb[2];
-#ifdef ABL_NO_LDSREAD
-      if (kt == 0) {
-#endif
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         fa[i] = *(const bf16x8*)(As + a_off[i] + ((chunk ^ a_swz[i]) << 4));
         fb[i] = *(const bf16x8*)(Bs + b_off[i] + ((chunk ^ b_swz[i]) << 4));
       }
-#ifdef ABL_NO_LDSREAD
-      abl_a[s][0] = fa[0]; abl_a[s][1] = fa[1]; abl_b[s][0] = fb[0]; abl_b[s][1] = fb[1];
-      } else { fa[0] = abl_a[s][0]; fa[1] = abl_a[s][1]; fb[0] = abl_b[s][0]; fb[1] = abl_b[s][1]; }
-#endif
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll

@@ -1,5 +1,5 @@
 // Large-tile variant of the bf16 MFMA GEMM for the big-M projections (QKV, attention out-proj, fc2):
-// 256 x BN x 64 tiles, 512 threads = 8 waves, ONE workgroup per CU.
+// 256 x 256 x 64 tiles, 8 or 16 waves, ONE persistent workgroup per CU.
 //
 // Why a second kernel: in the 128x128 kernel every v_mfma_f32_32x32x16 (32 cycles of matrix pipe) is accompanied by
 // 0.5 LDS-DMA issues (~60 cycles each) and 1.0 ds_read_b128 (~23 cycles each) in the wave's own instruction stream,
@@ -8,8 +8,10 @@
 // cuts the fragment reads to 0.75; 256 x 128 (64 x 64 per wave) keeps more tiles in flight for N = 768 and affords a
 // three-deep ring.
 //
-//   BN = 256: waves 2(M) x 4(N), wave tile 128 x 64, LDS ring 2 x 64 KiB  (prefetch distance 1 tile = 32 MFMAs/wave)
-//   BN = 128: waves 4(M) x 2(N), wave tile  64 x 64, LDS ring 2 x 48 KiB
+//   NW =  8: waves 2(M) x 4(N), wave tile 128 x 64 (0.75 fragment reads per MFMA), two waves per SIMD
+//   NW = 16: waves 4(M) x 4(N), wave tile  64 x 64 (1.0 reads per MFMA), FOUR waves per SIMD (<= 128 VGPRs) — more
+//            waves to cover each other's DMA-issue / LDS-read stalls at the price of LDS bandwidth
+//   LDS ring 2 x 64 KiB (prefetch distance 1 tile).
 //
 // Staging, swizzle, fragment layout and the LDS-staged vector epilogues are those of gemm.hip.h.
 #pragma once
@@ -23,20 +25,21 @@
 #define RSTAMP(slot) do {} while (0)
 #endif
 
-template <int BN> struct G256 {
-  static constexpr int BM = 256;
-  static constexpr int WM = BN == 256 ? 2 : 4;          // waves along M
-  static constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
+template <int NW> struct G256 {
+  static constexpr int BM = 256, BN = 256;
+  static constexpr int WM = NW == 8 ? 2 : 4;            // waves along M
+  static constexpr int WN = 4;                          // waves along N
   static constexpr int TM = BM / WM / 32;               // 32x32 MFMA tiles per wave along M (4 or 2)
   static constexpr int TN = 2;
-  static constexpr int S = 2;                           // ring depth
   static constexpr int A_BYTES = BM * 128;              // 256 rows x 64 bf16
   static constexpr int B_BYTES = BN * 128;
-  static constexpr int STAGE = A_BYTES + B_BYTES;
-  static constexpr int LDS = S * STAGE;                 // 131072 / 147456
-  static constexpr int GA = BM / 8 / 8;                 // LDS-DMA pieces per wave per stage (A): 4
-  static constexpr int GB = BN / 8 / 8;                 // (B): 4 / 2
-  static constexpr int G = GA + GB;
+  static constexpr int STAGE = A_BYTES + B_BYTES;       // 65536
+  static constexpr int LDS = 2 * STAGE;                 // 131072
+  static constexpr int GA = BM / 8 / NW;                // LDS-DMA pieces per wave per stage (A): 4 / 2
+  static constexpr int GB = BN / 8 / NW;
+  static constexpr int STG = STAGE / NW;                // wave-private epilogue staging bytes inside slot 1
+  static constexpr int ROWS16 = STG / 128;              // bf16 staging rows per pass (64 / 32)
+  static constexpr int ROWS32 = STG / 256;              // fp32 staging rows per pass (32 / 16)
 };
 
 // PERSISTENT: the grid is one workgroup per CU (or fewer tiles); each workgroup walks tiles wg, wg+G, wg+2G, ...
@@ -44,10 +47,10 @@ template <int BN> struct G256 {
 // tile's HBM latency) — measured 46 % of the tile time for K = 768.  Here the NEXT tile's first K-stage is issued by
 // LDS-DMA into ring slot 0 right after the main loop, and the epilogue stages through slot 1, so the DMA flight,
 // the address set-up and the bias load overlap the epilogue's VALU / store work and no launch sits in between.
-template <int EPI, int BN>
-__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmArgs g) {
-  using C = G256<BN>;
-  static_assert(C::S == 2 && BN == 256, "the persistent schedule below is written for the two-slot 256 x 256 ring");
+template <int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm256_bf16_kernel(const GemmArgs g) {
+  using C = G256<NW>;
+  constexpr int BN = C::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -74,14 +77,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmArgs g) 
     m0 = tm * C::BM; n0 = tn * BN;
 #pragma unroll
     for (int i = 0; i < C::GA; ++i) {
-      const int row = (wave + 8 * i) * 8 + (lane >> 3);
+      const int row = (wave + NW * i) * 8 + (lane >> 3);
       const int c_src = (lane & 7) ^ ((row >> 1) & 7);
       int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
       a_src[i] = g.A + (size_t)gr * g.lda + c_src * 8;
     }
 #pragma unroll
     for (int i = 0; i < C::GB; ++i) {
-      const int row = (wave + 8 * i) * 8 + (lane >> 3);
+      const int row = (wave + NW * i) * 8 + (lane >> 3);
       const int c_src = (lane & 7) ^ ((row >> 1) & 7);
       w_src[i] = g.W + (size_t)(n0 + row) * g.ldw + c_src * 8;
     }
@@ -89,9 +92,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmArgs g) 
   auto stage = [&](int slot, int kt) {
     char* base = smem + slot * C::STAGE;
 #pragma unroll
-    for (int i = 0; i < C::GB; ++i) glds16(w_src[i] + kt * GEMM_BK, base + C::A_BYTES + (wave + 8 * i) * 1024);
+    for (int i = 0; i < C::GB; ++i) glds16(w_src[i] + kt * GEMM_BK, base + C::A_BYTES + (wave + NW * i) * 1024);
 #pragma unroll
-    for (int i = 0; i < C::GA; ++i) glds16(a_src[i] + kt * GEMM_BK, base + (wave + 8 * i) * 1024);
+    for (int i = 0; i < C::GA; ++i) glds16(a_src[i] + kt * GEMM_BK, base + (wave + NW * i) * 1024);
   };
 
   const int nk = g.K / GEMM_BK;
@@ -155,19 +158,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmArgs g) 
       bias_pre[0] = g.bias[n0 + wn * 64 + l31]; bias_pre[1] = g.bias[n0 + wn * 64 + 32 + l31];
       stage(0, 0);
     }
-    char* stg = smem + C::STAGE + wave * 8192;       // wave-private 8 KiB inside slot 1
+    char* stg = smem + C::STAGE + wave * C::STG;     // wave-private staging inside slot 1
     if (EPI == EPI_BF16) {
+      constexpr int PASSES = C::TM * 32 / C::ROWS16, APP = C::ROWS16 / 32;   // 32-row sub-tiles per pass
 #pragma unroll
-      for (int h = 0; h < C::TM / 2; ++h) {          // 64 rows per pass
+      for (int h = 0; h < PASSES; ++h) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const float bias = b ? bias1 : bias0;
           char* const stc = stg + (b * 32 + l31) * 2;
 #pragma unroll
-          for (int a2 = 0; a2 < 2; ++a2)
+          for (int a2 = 0; a2 < APP; ++a2)
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
-              const int a = h * 2 + a2;
+              const int a = h * APP + a2;
               const int rw = a2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
               const bf16x2 ov = __builtin_bit_cast(bf16x2, pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias));
               *(bf16*)(stc + rw * 128) = ov[0];
@@ -177,48 +181,53 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(const GemmArgs g) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (wave_cols_ok) {
 #pragma unroll
-          for (int it = 0; it < 8; ++it) {
+          for (int it = 0; it < C::ROWS16 / 8; ++it) {
             const int r = it * 8 + (lane >> 3), c = (lane & 7) * 8;
             const bf16x8 v = *(const bf16x8*)(stg + r * 128 + c * 2);
-            const int m = row0 + h * 64 + r;
+            const int m = row0 + h * C::ROWS16 + r;
             if (m < g.M) *(bf16x8*)(g.out + (size_t)m * g.ldo + col0 + c) = v;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-    } else {   // EPI_RESID: per 32-row sub-tile, fp32 staging [32][64] then float4 read-modify-write of x
+    } else {   // EPI_RESID: fp32 staging of ROWS32 rows x 64 cols per pass, then float4 read-modify-write of x
       const int c = (lane & 15) * 4;
+      constexpr int PPA = 32 / C::ROWS32;            // passes per 32-row sub-tile (1 or 2)
+      constexpr int IT = C::ROWS32 / 4;              // float4 rows handled per lane per pass (8 or 4)
 #pragma unroll
-      for (int a = 0; a < C::TM; ++a) {
-        f32x4 xin[8];
-        float* dst[8];
-        if (wave_cols_ok) {
+      for (int a = 0; a < C::TM; ++a)
 #pragma unroll
-          for (int it = 0; it < 8; ++it) {
-            const int m = row0 + a * 32 + it * 4 + (lane >> 4);
-            const int mc = m < g.M ? m : g.M - 1;
-            dst[it] = g.x + (size_t)mc * g.ldx + col0 + c;
-            xin[it] = *(const f32x4*)dst[it];
+        for (int hp = 0; hp < PPA; ++hp) {
+          const int rbase = row0 + a * 32 + hp * C::ROWS32;
+          f32x4 xin[IT];
+          float* dst[IT];
+          if (wave_cols_ok) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+              const int m = rbase + it * 4 + (lane >> 4);
+              const int mc = m < g.M ? m : g.M - 1;
+              dst[it] = g.x + (size_t)mc * g.ldx + col0 + c;
+              xin[it] = *(const f32x4*)dst[it];
+            }
           }
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = hp * (16 / PPA); i < (hp + 1) * (16 / PPA); ++i) {
+              const int rw = (i & 3) + 8 * (i >> 2) + 4 * lh - hp * C::ROWS32;     // row inside this pass
+              *(float*)(stg + rw * 256 + (b * 32 + l31) * 4) = bf16_round(acc[a][b][i] + (b ? bias1 : bias0));
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (wave_cols_ok) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+              const int r = it * 4 + (lane >> 4);
+              const f32x4 v = *(const f32x4*)(stg + r * 256 + c * 4);
+              if (rbase + r < g.M) *(f32x4*)dst[it] = xin[it] + v;
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the staging
         }
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int rw = (i & 3) + 8 * (i >> 2) + 4 * lh;
-            *(float*)(stg + rw * 256 + (b * 32 + l31) * 4) = bf16_round(acc[a][b][i] + (b ? bias1 : bias0));
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (wave_cols_ok) {
-#pragma unroll
-          for (int it = 0; it < 8; ++it) {
-            const int r = it * 4 + (lane >> 4);
-            const f32x4 v = *(const f32x4*)(stg + r * 256 + c * 4);
-            if (row0 + a * 32 + r < g.M) *(f32x4*)dst[it] = xin[it] + v;
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next sub-tile overwrites the staging
-      }
     }
   }
   STAMP(59);

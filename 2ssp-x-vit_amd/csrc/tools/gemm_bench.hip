@@ -19,11 +19,11 @@ template <int EPI, int SCORE = 0> static void launch(const GemmArgs& g, hipStrea
 }
 
 static int nCU = 256;
-template <int EPI, int BN> static void launch256(GemmArgs g, hipStream_t s) {
+template <int EPI, int NW> static void launch256(GemmArgs g, hipStream_t s) {
   static bool done = false;
-  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<BN>::LDS)); done = true; }
-  g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, BN>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(512), G256<BN>::LDS, s, g);
+  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<NW>::LDS)); done = true; }
+  g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, NW>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(NW * 64), G256<NW>::LDS, s, g);
 }
 
 int main(int argc, char** argv) {
@@ -53,7 +53,8 @@ int main(int argc, char** argv) {
   auto run = [&]() {
     switch (epi) { case 0: launch<EPI_BF16>(g, s); break; case 1: launch<EPI_RESID>(g, s); break; case 2: launch<EPI_FC1, 1>(g, s); break; case 5: launch<EPI_FC1, 2>(g, s); break; case 6: launch<EPI_FC1, 0>(g, s); break;
                    case 3: launch<EPI_PATCH>(g, s); break; case 4: launch<EPI_F32>(g, s); break;
-                   case 10: launch256<EPI_BF16, 256>(g, s); break; case 11: launch256<EPI_RESID, 256>(g, s); break;
+                   case 10: launch256<EPI_BF16, 8>(g, s); break; case 11: launch256<EPI_RESID, 8>(g, s); break;
+                   case 30: launch256<EPI_BF16, 16>(g, s); break; case 31: launch256<EPI_RESID, 16>(g, s); break;
                    default: break; }
   };
   if (epi >= 10) {   // verify the large-tile kernel against the (oracle-validated) 128x128 kernel, bit for bit

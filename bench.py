@@ -37,6 +37,16 @@ import torch  # noqa: E402
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
+def pmc_traffic():
+    """HBM bytes per fc1 launch (launch-weighted over the same launch mix), from the committed rocprofv3 PMC passes
+    (scripts/pmc_traffic.sh -> profiles/r01_pmc_traffic.json; counters cannot be read from inside the process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return int(json.load(f)["fc1_family"]["avg_hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 class _MetaBatch(dict):
     """Placeholder for a batch owned by another rank: only its size is ever read."""
 
@@ -213,7 +223,7 @@ def main():
             ach = prof.flops / (prof.total_ms * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel<EPI_FC1,*> (fc1 + bias + erf-GELU [+ fused L2 partials])",
                                 "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
                                 "flops_per_launch_avg": prof.flops / prof.launches,
                                 "shapes": f"[{args.batch * tokens} | {n_eval * tokens} | {n_eval}] x {d_int} x {dim} (stage-1 batch | search chunk | CLS tail)"}
