@@ -8,7 +8,8 @@ import collections, csv, glob, json, sys
 
 
 def load(d, counter):
-    f = glob.glob(d + "/*/*_counter_collection.csv") or glob.glob(d + "/*_counter_collection.csv")
+    import os
+    f = sorted(glob.glob(d + "/*/*_counter_collection.csv") or glob.glob(d + "/*_counter_collection.csv"), key=os.path.getmtime, reverse=True)
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] == counter:
