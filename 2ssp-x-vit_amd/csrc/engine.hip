@@ -151,8 +151,9 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
 template <int EPI, int SCORE = 0>
 static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
   if (g.K % GEMM_BK) return fail(SSP2_EINVAL, "GEMM K=%d not a multiple of %d", g.K, GEMM_BK);
-  if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID) {
-    if (g.M >= kBigTileMinRows && !getenv("SSP2_NO_BIG_TILES")) return launch_gemm256<EPI>(e, g, klass);
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID || (EPI == EPI_FC1 && SCORE == 0)) {
+    static const bool fc1_big = !getenv("SSP2_FC1_SMALL_TILES");
+    if (g.M >= kBigTileMinRows && !(EPI == EPI_FC1 && (g.out2 || !fc1_big)) && !getenv("SSP2_NO_BIG_TILES")) return launch_gemm256<EPI>(e, g, klass);
   }
   g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
   if (g.tiles_m <= 0 || g.tiles_n <= 0) return fail(SSP2_EINVAL, "empty GEMM");

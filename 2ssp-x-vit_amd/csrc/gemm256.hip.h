@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void gemm256_bf16_kernel(const GemmArgs g)
       stage(0, 0);
     }
     char* stg = smem + C::STAGE + wave * C::STG;     // wave-private staging inside slot 1
-    if (EPI == EPI_BF16) {
+    if (EPI == EPI_BF16 || EPI == EPI_FC1) {   // EPI_FC1 here = bias + erf-GELU, no scoring (evaluation passes)
       constexpr int PASSES = C::TM * 32 / C::ROWS16, APP = C::ROWS16 / 32;   // 32-row sub-tiles per pass
 #pragma unroll
       for (int h = 0; h < PASSES; ++h) {
@@ -173,7 +173,13 @@ __global__ __launch_bounds__(NW * 64) void gemm256_bf16_kernel(const GemmArgs g)
             for (int i = 0; i < 16; i += 2) {
               const int a = h * APP + a2;
               const int rw = a2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-              const bf16x2 ov = __builtin_bit_cast(bf16x2, pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias));
+              uint32_t pk = pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias);
+              if (EPI == EPI_FC1) {
+                f32x2 pre; pre.x = bf16lo_f32(pk); pre.y = bf16hi_f32(pk);
+                const f32x2 gl = gelu_erf_fast2(pre);
+                pk = pack_bf16x2(gl.x, gl.y);
+              }
+              const bf16x2 ov = __builtin_bit_cast(bf16x2, pk);
               *(bf16*)(stc + rw * 128) = ov[0];
               *(bf16*)(stc + (rw + 1) * 128) = ov[1];
             }

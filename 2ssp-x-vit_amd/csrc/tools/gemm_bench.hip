@@ -54,15 +54,15 @@ int main(int argc, char** argv) {
     switch (epi) { case 0: launch<EPI_BF16>(g, s); break; case 1: launch<EPI_RESID>(g, s); break; case 2: launch<EPI_FC1, 1>(g, s); break; case 5: launch<EPI_FC1, 2>(g, s); break; case 6: launch<EPI_FC1, 0>(g, s); break;
                    case 3: launch<EPI_PATCH>(g, s); break; case 4: launch<EPI_F32>(g, s); break;
                    case 10: launch256<EPI_BF16, 8>(g, s); break; case 11: launch256<EPI_RESID, 8>(g, s); break;
-                   case 30: launch256<EPI_BF16, 16>(g, s); break; case 31: launch256<EPI_RESID, 16>(g, s); break;
+                   case 12: launch256<EPI_FC1, 8>(g, s); break; case 30: launch256<EPI_BF16, 16>(g, s); break; case 31: launch256<EPI_RESID, 16>(g, s); break;
                    default: break; }
   };
   if (epi >= 10) {   // verify the large-tile kernel against the (oracle-validated) 128x128 kernel, bit for bit
-    const bool resid = (epi % 10) == 1;
+    const bool resid = (epi % 10) == 1, fc1 = (epi % 10) == 2;
     size_t xe = (size_t)(M + M / 196 + 2) * Npad, oe = (size_t)M * Npad;
     CK(hipMemset(x, 0, xe * 4)); CK(hipMemset(out, 0, oe * 2));
     GemmArgs r = g; r.tiles_m = (M + 127) / 128; r.tiles_n = Npad / 128;
-    if (resid) launch<EPI_RESID>(r, s); else launch<EPI_BF16>(r, s);
+    if (resid) launch<EPI_RESID>(r, s); else if (fc1) launch<EPI_FC1, 0>(r, s); else launch<EPI_BF16>(r, s);
     CK(hipStreamSynchronize(s));
     std::vector<float> xr(resid ? xe : 0); std::vector<uint16_t> orf(resid ? 0 : oe);
     if (resid) CK(hipMemcpy(xr.data(), x, xe * 4, hipMemcpyDeviceToHost)); else CK(hipMemcpy(orf.data(), out, oe * 2, hipMemcpyDeviceToHost));
