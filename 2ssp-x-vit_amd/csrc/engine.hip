@@ -18,6 +18,7 @@
 #include "attn.hip.h"
 #include "gemm256.hip.h"
 #include "misc.hip.h"
+#include "preproc.hip.h"
 
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -622,6 +623,88 @@ int ssp2_profile_end(ssp2_handle e, double* total_ms, int64_t* launches, double*
   if (gemm_flops) *gemm_flops = e->prof_flops;
   e->prof_events.clear();
   e->prof_class = -1;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ f4: input pipeline
+struct ssp2_preproc {
+  int in_h = 0, in_w = 0, out = 0, ks_h = 0, ks_v = 0;
+  int *bounds_h = nullptr, *kk_h = nullptr, *bounds_v = nullptr, *kk_v = nullptr;
+  float mean[3], sd[3];
+};
+
+static double bicubic_filter(double x) {                 // Pillow Resample.c, a = -0.5
+  const double a = -0.5;
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+
+// Pillow precompute_coeffs + normalize_coeffs_8bpc for the full input range [0, in_size)
+static int pil_coeffs(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& kk) {
+  const double scale = (double)in_size / out_size;
+  double filterscale = scale;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 2.0 * filterscale;
+  const int ksize = (int)ceil(support) * 2 + 1;
+  bounds.assign((size_t)out_size * 2, 0);
+  kk.assign((size_t)out_size * ksize, 0);
+  std::vector<double> pre(ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    double ww = 0.0;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    int x = 0;
+    for (; x < xmax; ++x) { const double w = bicubic_filter((x + xmin - center + 0.5) * ss); pre[x] = w; ww += w; }
+    for (x = 0; x < xmax; ++x) if (ww != 0.0) pre[x] /= ww;
+    for (; x < ksize; ++x) pre[x] = 0;
+    for (x = 0; x < ksize; ++x)
+      kk[(size_t)xx * ksize + x] = pre[x] < 0 ? (int)(-0.5 + pre[x] * (1 << PREPROC_PRECISION_BITS)) : (int)(0.5 + pre[x] * (1 << PREPROC_PRECISION_BITS));
+    bounds[2 * xx] = xmin; bounds[2 * xx + 1] = xmax;
+  }
+  return ksize;
+}
+
+int ssp2_preproc_create(int in_h, int in_w, int out_size, const float* mean3, const float* std3, ssp2_preproc_handle* out) {
+  if (!out || !mean3 || !std3 || in_h <= 0 || in_w <= 0 || out_size <= 0) return fail(SSP2_EINVAL, "bad preproc arguments");
+  auto* p = new ssp2_preproc();
+  p->in_h = in_h; p->in_w = in_w; p->out = out_size;
+  for (int i = 0; i < 3; ++i) { p->mean[i] = mean3[i]; p->sd[i] = std3[i]; }
+  std::vector<int> bh, kh, bv, kv;
+  p->ks_h = pil_coeffs(in_w, out_size, bh, kh);
+  p->ks_v = pil_coeffs(in_h, out_size, bv, kv);
+  auto up = [](int** d, const std::vector<int>& v) {
+    if (hipMalloc((void**)d, v.size() * 4) != hipSuccess) return false;
+    return hipMemcpy(*d, v.data(), v.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  if (!up(&p->bounds_h, bh) || !up(&p->kk_h, kh) || !up(&p->bounds_v, bv) || !up(&p->kk_v, kv)) { ssp2_preproc_destroy(p); return fail(SSP2_ENOMEM, "preproc tables"); }
+  *out = p;
+  return 0;
+}
+
+int ssp2_preproc_destroy(ssp2_preproc_handle p) {
+  if (!p) return 0;
+  hipFree(p->bounds_h); hipFree(p->kk_h); hipFree(p->bounds_v); hipFree(p->kk_v);
+  delete p;
+  return 0;
+}
+
+int ssp2_preproc_run(ssp2_preproc_handle p, void* stream, const uint8_t* img_dev, int n, const uint8_t* hflip_dev, uint8_t* tmp_dev,
+                     float* out_dev, uint8_t* out_u8_dev) {
+  if (!p || !img_dev || !tmp_dev || !out_dev || n <= 0) return fail(SSP2_EINVAL, "bad preproc_run arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const long t1 = (long)n * p->in_h * p->out * 3, t2 = (long)n * 3 * p->out * p->out;
+  hipLaunchKernelGGL(resize_h_u8_kernel, dim3((unsigned)std::min<long>((t1 + 255) / 256, 65536)), dim3(256), 0, s, img_dev, tmp_dev, n, p->in_h, p->in_w,
+                     p->out, p->bounds_h, p->kk_h, p->ks_h);
+  hipLaunchKernelGGL(resize_v_norm_kernel, dim3((unsigned)std::min<long>((t2 + 255) / 256, 65536)), dim3(256), 0, s, tmp_dev, out_dev, out_u8_dev, n, p->in_h,
+                     p->out, p->out, p->bounds_v, p->kk_v, p->ks_v, hflip_dev, p->mean[0], p->mean[1], p->mean[2], p->sd[0], p->sd[1], p->sd[2]);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

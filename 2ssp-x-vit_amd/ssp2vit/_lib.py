@@ -17,7 +17,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 SYMBOLS = [
     "ssp2_abi_version", "ssp2_last_error", "ssp2_create", "ssp2_destroy", "ssp2_set_stream", "ssp2_load_tensor",
     "ssp2_embed", "ssp2_layers", "ssp2_head", "ssp2_tail", "ssp2_prune_ffn", "ssp2_drop_attention", "ssp2_d_int", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
-    "ssp2_tokens", "ssp2_workspace_bytes",
+    "ssp2_tokens", "ssp2_workspace_bytes", "ssp2_preproc_create", "ssp2_preproc_run", "ssp2_preproc_destroy",
 ]
 
 T_KINDS = ["patch_w", "patch_b", "cls", "pos", "ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
@@ -90,6 +90,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_tokens.argtypes = [vp]
     lib.ssp2_workspace_bytes.argtypes = [vp]
     lib.ssp2_workspace_bytes.restype = C.c_size_t
+    lib.ssp2_preproc_create.argtypes = [i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(vp)]
+    lib.ssp2_preproc_run.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.ssp2_preproc_destroy.argtypes = [vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("ssp2_last_error", "ssp2_workspace_bytes"):

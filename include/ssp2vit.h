@@ -124,6 +124,17 @@ int ssp2_d_int(ssp2_handle h, int layer);
 int ssp2_act_l2_accum(void* hip_stream, const void* act_dev, int dtype, int n, int tokens, int d, int ld,
                       int score_chain, int group, float* norms_ws_dev, float* out_dev, size_t out_stride);
 
+/* f4 — input pipeline on the device, the step in front of the path (adaptation-for-Pures-framework/auto_2ssp.py:
+ * 290-301): uint8 HWC images -> bicubic resize to out x out (Pillow's 8-bit fixed-point resampler, bit-identical) ->
+ * optional horizontal flip of the resized image -> /255 -> (x - mean) / std -> fp32 NCHW.
+ *   img_dev u8 [n, in_h, in_w, 3]; hflip_dev u8 [n] or NULL; tmp_dev u8 [n, in_h, out, 3] scratch;
+ *   out_dev f32 [n, 3, out, out]; out_u8_dev u8 [n, out, out, 3] or NULL (the resized image itself, for checks). */
+typedef struct ssp2_preproc* ssp2_preproc_handle;
+int ssp2_preproc_create(int in_h, int in_w, int out_size, const float* mean3, const float* std3, ssp2_preproc_handle* out);
+int ssp2_preproc_run(ssp2_preproc_handle p, void* hip_stream, const uint8_t* img_dev, int n, const uint8_t* hflip_dev,
+                     uint8_t* tmp_dev, float* out_dev, uint8_t* out_u8_dev);
+int ssp2_preproc_destroy(ssp2_preproc_handle p);
+
 /* per-kernel-class HIP-event timing (bench.py roofline leg).  klass: see SSP2_K_* */
 enum { SSP2_K_GEMM_FC1 = 0, SSP2_K_GEMM_FC2, SSP2_K_GEMM_QKV, SSP2_K_GEMM_PROJ, SSP2_K_GEMM_PATCH,
        SSP2_K_GEMM_HEAD, SSP2_K_ATTN, SSP2_K_LN, SSP2_K_SCORE_FINISH, SSP2_K_ACT_L2, SSP2_K_OTHER,

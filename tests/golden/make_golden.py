@@ -260,7 +260,28 @@ def artifact_tool_cases():
     print("[golden] artifact_tools.json written:", len(out["cases"]), "cases")
 
 
+def preprocess_cases():
+    """Input pipeline.  torchvision is not installed; its Resize on PIL images IS `Image.resize`
+    (third-party Pillow, importable here), so the resized uint8 images are captured from Pillow itself."""
+    from PIL import Image
+    rng = np.random.default_rng(21)
+    rec = {}
+    for tag, (h, w), n in (("cifar", (32, 32), 2), ("nonsquare", (40, 48), 1), ("down", (256, 300), 1)):
+        imgs = rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8)
+        imgs[0, :4, :4] = 255; imgs[0, -4:, -4:] = 0                  # saturated corners: exercises the 8-bit clip
+        out = np.stack([np.asarray(Image.fromarray(im, "RGB").resize((224, 224), Image.BICUBIC)) for im in imgs])
+        rec[f"{tag}.in"] = imgs
+        rec[f"{tag}.out"] = out
+    import PIL
+    rec["pillow_version"] = np.asarray(PIL.__version__)
+    np.savez_compressed(os.path.join(HERE, "preprocess_pil.npz"), **rec)
+    print("[golden] preprocess_pil.npz written (Pillow", PIL.__version__, ")")
+
+
 if __name__ == "__main__":
+    if "--preprocess-only" in sys.argv:
+        preprocess_cases()
+        sys.exit(0)
     if "--artifacts-only" in sys.argv:
         artifact_tool_cases()
         sys.exit(0)
@@ -270,3 +291,4 @@ if __name__ == "__main__":
     planner_cases()
     heuristic_and_exports()
     artifact_tool_cases()
+    preprocess_cases()

@@ -442,3 +442,30 @@ def test_iterative_depth_search_matches_brute_force_and_oracle(gpu):
     g_first = vp._top1_counts(model, batches, "cuda", 5, attn_skip=[o_removed[0]])[0] / 16
     assert abs(g_first - trace[0][1]) <= 1 / 16 + 1e-9
     vp.release_engines()
+
+
+def test_gpu_input_pipeline_is_bit_identical_to_pillow_and_torchvision_chain(gpu):
+    """f4: Resize(BICUBIC) -> [flip] -> ToTensor -> Normalize on the device.  uint8 resize vs Pillow goldens
+    (up-scale 32->224, non-square, down-scale with a wider kernel), fp32 vs the torchvision arithmetic restated with
+    torch CPU ops ((x/255 - mean)/std in fp32): both bit-exact."""
+    from ssp2vit.preprocess import GpuPreprocessor
+    z = dict(np.load(os.path.join(GOLDEN, "preprocess_pil.npz")))
+    mean, std = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)                         # HF ViT processor (image_mean / image_std)
+    for tag in ("cifar", "nonsquare", "down"):
+        src, ref = torch.from_numpy(z[f"{tag}.in"]), torch.from_numpy(z[f"{tag}.out"])
+        pp = GpuPreprocessor(src.shape[1:3], 224, mean, std)
+        out, u8 = pp(src, return_u8=True)
+        assert torch.equal(u8.cpu(), ref), tag
+        t = ref.permute(0, 3, 1, 2).contiguous().to(torch.float32).div(255)                       # ToTensor
+        t = t.sub(torch.tensor(mean).view(1, 3, 1, 1)).div(torch.tensor(std).view(1, 3, 1, 1))    # Normalize
+        assert torch.equal(out.cpu(), t), tag
+        flip = torch.zeros(src.shape[0], dtype=torch.uint8); flip[0] = 1
+        outf = pp(src, hflip=flip).cpu()
+        assert torch.equal(outf[0], t[0].flip(-1)) and torch.equal(outf[1:], t[1:])
+    pp2 = GpuPreprocessor((32, 32), 224, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))           # ImageNet statistics
+    src = torch.from_numpy(z["cifar.in"])
+    t = torch.from_numpy(z["cifar.out"]).permute(0, 3, 1, 2).contiguous().to(torch.float32).div(255)
+    t = t.sub(torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)).div(torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+    assert torch.equal(pp2(src).cpu(), t)
+    with pytest.raises(ValueError):
+        pp2(src.float())
