@@ -38,7 +38,7 @@ class Ssp2Error(RuntimeError):
     pass
 
 
-def build_library(verbose: bool = False) -> str:
+def build_library(verbose: bool = False, only_if_stale: bool = False) -> str:
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Output stays in-tree: 2ssp-x-vit_amd/lib/."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -46,16 +46,40 @@ def build_library(verbose: bool = False) -> str:
            os.path.join(CSRC, "engine.hip"), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:          # one builder at a time (several ranks may start together)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if only_if_stale and not _needs_rebuild():
+            return LIB_PATH
+        tmp = LIB_PATH + f".tmp{os.getpid()}"
+        cmd[-1] = tmp
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        os.replace(tmp, LIB_PATH)
+        with open(HASH_PATH, "w") as f:
+            f.write(_source_hash())
     return LIB_PATH
 
 
+HASH_PATH = LIB_PATH + ".srchash"
+
+
+def _source_hash() -> str:
+    """Content hash of every source the library is built from (file mtimes do not survive the copy to a GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f)))
+    for s in srcs + [os.path.join(INCLUDE, "ssp2vit.h")]:
+        h.update(os.path.basename(s).encode())
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _needs_rebuild() -> bool:
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "ssp2vit.h")]
-    return any(os.path.getmtime(s) > t for s in srcs if os.path.isfile(s))
+    with open(HASH_PATH) as f:
+        return f.read().strip() != _source_hash()
 
 
 _lib: Optional[C.CDLL] = None
@@ -68,7 +92,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if _needs_rebuild():
         if not build_if_missing:
             raise Ssp2Error(f"{LIB_PATH} missing or stale; run `python -c 'import __graft_entry__ as g; g.build()'`")
-        build_library()
+        build_library(only_if_stale=True)
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64p = C.c_void_p, C.c_int, C.POINTER(C.c_int64)
     lib.ssp2_abi_version.restype = i32
