@@ -469,3 +469,37 @@ def test_gpu_input_pipeline_is_bit_identical_to_pillow_and_torchvision_chain(gpu
     assert torch.equal(pp2(src).cpu(), t)
     with pytest.raises(ValueError):
         pp2(src.float())
+
+
+def test_prune_masks_identical_to_oracle_where_the_cut_margin_allows(gpu):
+    """North-star property: identical pruning masks.  Masks are a discrete function of the scores, so they are equal
+    exactly when the score gap at the keep/prune cut exceeds the fp error between the two implementations.  With
+    fc1 rows spread log-uniformly (x[1/4,4]) the gap at the cut is far above the measured 5e-4 score
+    error in almost every block; blocks whose gap is below 4x the tolerance are reported, not asserted."""
+    from oracle import ref_cpu
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=0, std=0.02, eps=1e-6, spread=4.0)
+    model = build_from_flat(w, "timm")
+    g = torch.Generator().manual_seed(1)
+    batches = [{"pixel_values": torch.randn(16, 3, 224, 224, generator=g)} for _ in range(2)]
+    gpu_imps = vp._compute_ffn_activation_importance(model, batches, device="cuda")
+    ref_imps = ref_cpu.ffn_activation_importance(model, batches, chain="fp32")
+    n_prune = 304                                       # the planner's t for ViT-Ti/16 @ 37.5 %
+    g_masks, _ = ref_cpu.width_prune_selection(gpu_imps, [n_prune] * 12, min_remaining=256)
+    r_masks, _ = ref_cpu.width_prune_selection(ref_imps, [n_prune] * 12, min_remaining=256)
+    asserted, same = 0, 0
+    for l in range(12):
+        s = torch.sort(ref_imps[l], descending=True).values
+        k = s.numel() - n_prune
+        margin = float((s[k - 1] - s[k]) / s[k - 1])
+        same += sum(a == b for a, b in zip(g_masks[l], r_masks[l]))
+        if margin > 1e-3:                               # gap above twice the measured score error (<= 5e-4)
+            assert g_masks[l] == r_masks[l], (l, margin)
+            asserted += 1
+        else:
+            print(f"[mask-parity] block {l}: cut margin {margin:.2e} inside the fp error band, not asserted "
+                  f"(overlap {sum(a == b for a, b in zip(g_masks[l], r_masks[l]))}/768)")
+    assert asserted >= 9 and same >= 12 * 768 - 4       # at most two swapped pairs over the whole model
+    vp.release_engines()
