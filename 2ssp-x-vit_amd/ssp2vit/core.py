@@ -171,7 +171,7 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
     counts = torch.tensor([0, total], dtype=torch.int64, device=correct_dev.device if correct_dev is not None else "cpu")
     if correct_dev is not None:
         counts[0] = correct_dev[0]
-    if ws > 1:
+    if ws > 1 or (_dist.FORCE_COLLECTIVES and _dist._initialised()):
         counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
     c = counts.to("cpu")
     return int(c[0]), int(c[1])
@@ -220,7 +220,7 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
         counts = torch.zeros(L + 2, dtype=torch.int64)
     else:
         counts = torch.cat([counts_dev, torch.tensor([total], dtype=torch.int64, device=counts_dev.device)])
-    if ws > 1:
+    if ws > 1 or (_dist.FORCE_COLLECTIVES and _dist._initialised()):
         counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
     c = counts.to("cpu").tolist()
     return c[-2], c[:-2], c[-1]

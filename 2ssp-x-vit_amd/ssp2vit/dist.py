@@ -9,9 +9,18 @@ Exchange steps (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gl
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
+
+# debugging aid: run the collectives even in a one-rank process group (exercises the RCCL calls on a 1-GPU box)
+FORCE_COLLECTIVES = bool(os.environ.get("SSP2_FORCE_COLLECTIVES"))
+
+
+def _initialised() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 def world(group=None) -> Tuple[int, int]:
@@ -31,7 +40,7 @@ def gather_batch_vectors(local: Sequence[Tuple[int, torch.Tensor]], n_batches_to
     Returns the vectors of ALL batches in global batch order, identical on every rank."""
     import torch.distributed as dist
     rank, ws = world(group)
-    if ws == 1:
+    if ws == 1 and not (FORCE_COLLECTIVES and _initialised()):
         return [v for _, v in sorted(local, key=lambda p: p[0])]
     if n_batches_total == 0:
         return []
@@ -55,7 +64,7 @@ def all_reduce_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
     """int64 tensor, summed over ranks in place (exact)."""
     import torch.distributed as dist
     _, ws = world(group)
-    if ws > 1:
+    if ws > 1 or (FORCE_COLLECTIVES and _initialised()):
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     return counts
 

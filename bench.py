@@ -119,7 +119,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and os.environ.get("SSP2_FORCE_COLLECTIVES")):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
@@ -166,7 +166,7 @@ def main():
         return imps, impact, masks, blocks
 
     def sync_all():
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -192,7 +192,7 @@ def main():
     sync_all(); s1_s = time.perf_counter() - t1
 
     el = torch.tensor([elapsed, s1_s], dtype=torch.float64, device=dev)
-    if world > 1:
+    if pg is not None:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed, s1_s = float(el[0]), float(el[1])
 
@@ -230,7 +230,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, weights)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

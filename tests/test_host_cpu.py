@@ -194,3 +194,20 @@ def test_report_writer(tmp_path):
     assert json.load(open(out["json"]))["plan"]["blocks_to_prune"] == 1
     md = open(out["md"]).read()
     assert md.startswith("# 2SSP ViT Pruning Report (t)") and "- Blocks to prune (Stage-2): 1 (0.2500)" in md
+
+
+def test_empty_and_limited_loaders_like_reference():
+    """No batches (or batch_limit=0): the reference returns zero scores (src/vit_pruning.py:197-198) and
+    correct/max(1,0) = 0.0 accuracy (:373) without ever calling the model — so no GPU is needed here either."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    w, batches, _ = load_tiny_golden("timm")
+    m = build_from_flat(w, "timm")
+    imps = vp._compute_ffn_activation_importance(m, [], device="cuda")
+    assert len(imps) == 4 and all(t.shape == (128,) and not t.any() for t in imps)
+    imps = vp._compute_ffn_activation_importance(m, batches, device="cuda", batch_limit=0)
+    assert all(not t.any() for t in imps)
+    assert vp.evaluate_top1(m, [], device="cuda") == 0.0
+    assert vp.evaluate_top1(m, batches, device="cuda", max_batches=0) == 0.0
+    base, cand, total = vp.depth_search_counts(m, [], "cuda", 5)
+    assert (base, cand, total) == (0, [0, 0, 0, 0], 0)
