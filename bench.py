@@ -218,10 +218,10 @@ def main():
             "selected_blocks": out[3], "pruned_neurons_per_block": plan.per_block_neurons_to_prune,
         }
         if prof is not None and prof.launches:
-            # dominant kernel family: fc1 (+bias +erf-GELU, + fused activation-L2 partials in stage 1), 128x128 tiles.
+            # dominant kernel family: fc1 (+bias +erf-GELU; + fused activation-L2 partials in stage 1).
             # achieved = algorithmic flops (2*M*N*K summed over the recorded launches) / summed HIP-event durations.
             ach = prof.flops / (prof.total_ms * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel<EPI_FC1,*> (fc1 + bias + erf-GELU [+ fused L2 partials])",
+            line["roofline"] = {"bound": "mfma", "kernel": "fc1 GEMM family: gemm_bf16_kernel<EPI_FC1,score> 128x128 (stage 1, fused L2 partials) + gemm256_bf16_kernel<EPI_FC1> 256x256 persistent (search passes); bias + erf-GELU fused",
                                 "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
