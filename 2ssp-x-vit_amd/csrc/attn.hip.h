@@ -22,7 +22,7 @@
 template <int DH, int NT, bool CLS_ONLY = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, int ld, const bf16* __restrict__ qsrc,
                                                       size_t q_img_stride, int q_ld, bf16* __restrict__ out,
-                                                      size_t o_img_stride, int ldo, int tokens, int dim, float scale) {
+                                                      size_t o_img_stride, int ldo, int tokens, int dim, float scale, RowMap rm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DT = (DH + 31) / 32;     // 32-row tiles of the O^T output (d_h padded up)
   constexpr int KS = DH / 16;            // k-steps of the QK^T product
@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int head = blockIdx.x, img = blockIdx.y;
-  const bf16* base = qkv + (size_t)img * tokens * ld + head * DH;
+  const size_t img_row = (size_t)row_of(rm, img);
+  const bf16* base = qkv + img_row * ld + head * DH;
 
   // ---- stage K, V (zero rows past `tokens`, zero V columns past d_h: 0 * garbage would be NaN-unsafe)
   for (int idx = tid; idx < NKEY * CH; idx += 256) {
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
   const int v_lane_off = (4 * lh + tr_q) * VSB + (16 * tr_g + 4 * tr_p) * 2;
 
-  const bf16* qbase = qsrc + (size_t)img * q_img_stride + head * DH;
+  const bf16* qbase = (CLS_ONLY ? qsrc + (size_t)img * q_img_stride : qsrc + img_row * ld) + head * DH;
   for (int qt = wave; qt < (CLS_ONLY ? 1 : NT); qt += 4) {   // wave-uniform trip count: EXEC stays full
     const int q = qt * 32 + l31;
     const int qc = q < tokens ? q : tokens - 1;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     }
     // ---- store: lane <-> query row, 4 consecutive d_h per 8-byte store
     if (CLS_ONLY ? (q == 0) : (q < tokens)) {
-      bf16* op = out + (size_t)img * o_img_stride + (size_t)q * ldo + head * DH;
+      bf16* op = (CLS_ONLY ? out + (size_t)img * o_img_stride : out + img_row * ldo) + (size_t)q * ldo + head * DH;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll

@@ -41,3 +41,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
+
+// Row layout of the token matrix.  group == 0: images are contiguous (row of image i = i * tokens).
+// group  > 0: the images are laid out in SLABS of `group` images (= one dataloader batch each), every slab padded to
+// `mpad` rows (a multiple of 256, so no GEMM tile straddles two slabs).  A sample then sits at the same offset inside
+// its slab whichever launch it is part of, which makes the per-tile partial sums of the fused stage-1 score — and so
+// the scores — independent of how many batches share a launch.
+struct RowMap { int tokens, group, mpad; };
+__host__ __device__ __forceinline__ long row_of(const RowMap r, int img) {
+  return r.group > 0 ? (long)(img / r.group) * r.mpad + (long)(img % r.group) * r.tokens : (long)img * r.tokens;
+}

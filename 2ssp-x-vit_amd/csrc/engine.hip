@@ -39,6 +39,18 @@ static int fail(int code, const char* fmt, ...) {
 
 static inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 
+// slab layout (common.hip.h RowMap): `group` images per slab, slabs padded to a multiple of 256 rows
+static inline RowMap make_rowmap(int tokens, int n, int group) {
+  RowMap r{tokens, 0, 0};
+  if (group > 0 && group < n) { r.group = group; r.mpad = ceil_to(group * tokens, 256); }
+  return r;
+}
+static inline long total_rows(const RowMap& r, int n) {
+  if (r.group <= 0) return (long)n * r.tokens;
+  const int full = n / r.group, rest = n - full * r.group;
+  return rest ? (long)full * r.mpad + (long)rest * r.tokens : (long)(full - 1) * r.mpad + (long)r.group * r.tokens;
+}
+
 // fp32 -> bf16 bits, round-to-nearest-even, NaN kept quiet (matches torch .to(bfloat16))
 static inline uint16_t f2bf(float f) {
   uint32_t u;
@@ -73,6 +85,7 @@ struct ssp2_engine {
   std::vector<int32_t> d_int;
   int tokens = 0, patches = 0, side = 0, dh = 0;
   int kpe = 0, kpe_pad = 0, ld_int_max = 0;
+  long rows_cap = 0;        // token-matrix rows the workspace is sized for
   hipStream_t stream = nullptr;
   int n_cu = 256;
   std::vector<void*> allocs;
@@ -170,15 +183,15 @@ static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
 }
 
 static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const float* g, const float* b, bf16* y,
-                     int out_ld, int rows, int D) {
+                     int out_ld, int rows, int D, RowMap gather = RowMap{0, 0, 0}) {
   ProfScope ps(e, SSP2_K_LN);
   dim3 grid((rows + 3) / 4), blk(256);
   if (D <= 256 * 1)
-    hipLaunchKernelGGL(layernorm_bf16_kernel<1>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
+    hipLaunchKernelGGL(layernorm_bf16_kernel<1>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather);
   else if (D <= 256 * 3)
-    hipLaunchKernelGGL(layernorm_bf16_kernel<3>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
+    hipLaunchKernelGGL(layernorm_bf16_kernel<3>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather);
   else if (D <= 256 * 8)
-    hipLaunchKernelGGL(layernorm_bf16_kernel<8>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps);
+    hipLaunchKernelGGL(layernorm_bf16_kernel<8>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather);
   else
     return fail(SSP2_EINVAL, "LayerNorm width %d > 2048 unsupported", D);
   HIPCHK(hipGetLastError());
@@ -186,7 +199,7 @@ static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const flo
 }
 
 template <int DH, int NT, bool CLS>
-static int launch_attn_t(ssp2_engine* e, int n) {
+static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
   constexpr int smem = NT * 32 * (DH * 2 + 16) + NT * 32 * 192;
   static bool attr_done = false;
   if (!attr_done) {
@@ -197,17 +210,17 @@ static int launch_attn_t(ssp2_engine* e, int n) {
   const int D = e->d.dim, ld = 3 * D;
   if (CLS)   // q from the compact CLS projection, only row 0 kept, compact [n, D] output
     hipLaunchKernelGGL((attn_fwd_kernel<DH, NT, true>), dim3(e->d.heads, n), dim3(256), smem, e->stream, e->qkvbuf, ld, e->q_cls,
-                       (size_t)D, 0, e->o_cls, (size_t)D, D, e->tokens, D, 1.0f / sqrtf((float)DH));
+                       (size_t)D, 0, e->o_cls, (size_t)D, D, e->tokens, D, 1.0f / sqrtf((float)DH), rm);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<DH, NT, false>), dim3(e->d.heads, n), dim3(256), smem, e->stream, e->qkvbuf, ld, e->qkvbuf,
-                       (size_t)e->tokens * ld, ld, e->obuf, (size_t)e->tokens * D, D, e->tokens, D, 1.0f / sqrtf((float)DH));
+                       (size_t)e->tokens * ld, ld, e->obuf, (size_t)e->tokens * D, D, e->tokens, D, 1.0f / sqrtf((float)DH), rm);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-static int launch_attn(ssp2_engine* e, int n, bool cls_only = false) {
+static int launch_attn(ssp2_engine* e, int n, RowMap rm, bool cls_only = false) {
   const int nt = (e->tokens + 31) / 32;
-#define ATTN_CASE(DH_, NT_) if (e->dh == DH_ && nt == NT_) return cls_only ? launch_attn_t<DH_, NT_, true>(e, n) : launch_attn_t<DH_, NT_, false>(e, n)
+#define ATTN_CASE(DH_, NT_) if (e->dh == DH_ && nt == NT_) return cls_only ? launch_attn_t<DH_, NT_, true>(e, n, rm) : launch_attn_t<DH_, NT_, false>(e, n, rm)
   ATTN_CASE(64, 7);   // 224/16: 197 tokens (Ti/S/B/L)
   ATTN_CASE(80, 9);   // 224/14: 257 tokens (H/14)
   ATTN_CASE(16, 1);   // reference smoke config: 32/16, 5 tokens
@@ -218,6 +231,9 @@ static int launch_attn(ssp2_engine* e, int n, bool cls_only = false) {
 #undef ATTN_CASE
   return fail(SSP2_EINVAL, "attention kernel not instantiated for d_h=%d, tokens=%d", e->dh, e->tokens);
 }
+
+static int act_l2_impl(void* stream, const void* act, int dtype, int n, RowMap rm, int d, int ld, int chain, int group,
+                       float* norms_ws, float* out, size_t out_stride);
 
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" {
@@ -276,7 +292,8 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
     TRY(mat_alloc(e, L.fc1, L.d_int, d.dim));
     TRY(mat_alloc(e, L.fc2, d.dim, L.d_int));
   }
-  const size_t M = (size_t)d.max_images * e->tokens;
+  e->rows_cap = (long)d.max_images * e->tokens + 16 * 256;     // slack: up to 16 padded slabs per call
+  const size_t M = (size_t)e->rows_cap;
   const size_t tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   TRY(dalloc(e, &e->a_pe, (size_t)d.max_images * e->patches * e->kpe_pad, true));
   TRY(dalloc(e, &e->hbuf, M * d.dim, true));
@@ -314,6 +331,7 @@ int ssp2_set_stream(ssp2_handle e, void* s) {
 }
 
 int ssp2_tokens(ssp2_handle e) { return e ? e->tokens : SSP2_EINVAL; }
+long ssp2_rows(ssp2_handle e, int n, int group) { return e ? total_rows(make_rowmap(e->tokens, n, group), n) : SSP2_EINVAL; }
 size_t ssp2_workspace_bytes(ssp2_handle e) { return e ? e->ws_bytes : 0; }
 
 static int upload_matrix(Mat& m, const float* host, size_t numel) {
@@ -371,18 +389,23 @@ int ssp2_load_tensor(ssp2_handle e, int kind, int layer, const float* host, size
   }
 }
 
-static int check_n(ssp2_engine* e, int n) {
+static int check_n(ssp2_engine* e, int n, int group = 0) {
   if (!e) return fail(SSP2_EINVAL, "null handle");
   if (n <= 0 || n > e->d.max_images) return fail(SSP2_ESTATE, "n=%d outside (0, max_images=%d]", n, e->d.max_images);
+  if (group < 0) return fail(SSP2_EINVAL, "group=%d", group);
+  if (total_rows(make_rowmap(e->tokens, n, group), n) > e->rows_cap) return fail(SSP2_ESTATE, "slab layout of %d images in groups of %d exceeds the workspace", n, group);
   return 0;
 }
 
-int ssp2_embed(ssp2_handle e, const float* pixels_dev, int n, float* x_dev) {
+int ssp2_embed(ssp2_handle e, const float* pixels_dev, int n, float* x_dev, int group) {
   int rc;
-  if ((rc = check_n(e, n))) return rc;
+  if ((rc = check_n(e, n, group))) return rc;
+  const RowMap rm = make_rowmap(e->tokens, n, group);
   if (!pixels_dev || !x_dev) return fail(SSP2_EINVAL, "null device pointer");
   if (!(e->patch.w_set && e->patch.b_set && e->misc_set[0] && e->misc_set[1])) return fail(SSP2_ESTATE, "patch/cls/pos weights not loaded");
   const int D = e->d.dim;
+  if (rm.group > 0)   // pad rows between slabs must hold finite values: they flow through LN / GEMMs (never scored)
+    HIPCHK(hipMemsetAsync(x_dev, 0, (size_t)total_rows(rm, n) * D * 4, e->stream));
   {
     ProfScope ps(e, SSP2_K_OTHER);
     const long total = (long)n * e->patches * (e->kpe_pad / 8);
@@ -390,25 +413,26 @@ int ssp2_embed(ssp2_handle e, const float* pixels_dev, int n, float* x_dev) {
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(im2col_patch_kernel, dim3(blocks), dim3(256), 0, e->stream, pixels_dev, e->a_pe, n, e->d.img,
                        e->d.patch, e->side, e->kpe, e->kpe_pad);
-    hipLaunchKernelGGL(cls_row_kernel, dim3((n * D + 255) / 256), dim3(256), 0, e->stream, x_dev, e->cls, e->pos, n, e->tokens, D);
+    hipLaunchKernelGGL(cls_row_kernel, dim3((n * D + 255) / 256), dim3(256), 0, e->stream, x_dev, e->cls, e->pos, n, rm, D);
     HIPCHK(hipGetLastError());
   }
   GemmArgs g{};
   g.A = e->a_pe; g.lda = e->kpe_pad; g.W = e->patch.w; g.ldw = e->patch.ld; g.bias = e->patch.b;
   g.M = n * e->patches; g.N = D; g.K = e->kpe_pad; g.tiles_n = e->patch.rows_pad / GEMM_BN;
-  g.x = x_dev; g.ldx = D; g.pos = e->pos; g.patches = e->patches;
+  g.x = x_dev; g.ldx = D; g.pos = e->pos; g.patches = e->patches; g.group = rm.group; g.mpad = rm.mpad; g.n_img = n;
   return launch_gemm<EPI_PATCH>(e, g, SSP2_K_GEMM_PATCH);
 }
 
 int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const uint8_t* attn_skip, int score_site,
                 int score_chain, int score_group, float* batch_scores, int score_ld) {
   int rc;
-  if ((rc = check_n(e, n))) return rc;
+  if ((rc = check_n(e, n, score_group))) return rc;
   if (!x) return fail(SSP2_EINVAL, "null x");
   if (l_begin < 0 || l_end > e->d.depth || l_begin > l_end) return fail(SSP2_EINVAL, "bad layer range [%d,%d)", l_begin, l_end);
   if (score_site < 0 || score_site > 2) return fail(SSP2_EINVAL, "bad score_site %d", score_site);
   if (score_site && (!batch_scores || score_ld < e->ld_int_max)) return fail(SSP2_EINVAL, "batch_scores needs ld >= %d", e->ld_int_max);
-  const int D = e->d.dim, M = n * e->tokens;
+  const RowMap rm = make_rowmap(e->tokens, n, score_group);
+  const int D = e->d.dim, M = (int)total_rows(rm, n);
   const int grp = (score_group <= 0 || score_group > n) ? n : score_group;
   const int n_groups = (n + grp - 1) / grp;
   const size_t group_stride = (size_t)e->d.depth * score_ld;
@@ -426,7 +450,7 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
       q.A = e->hbuf; q.lda = D; q.W = L.qkv.w; q.ldw = L.qkv.ld; q.bias = L.qkv.b;
       q.M = M; q.N = 3 * D; q.K = D; q.tiles_n = L.qkv.rows_pad / GEMM_BN; q.out = e->qkvbuf; q.ldo = 3 * D;
       if ((rc = launch_gemm<EPI_BF16>(e, q, SSP2_K_GEMM_QKV))) return rc;
-      if ((rc = launch_attn(e, n))) return rc;
+      if ((rc = launch_attn(e, n, rm))) return rc;
       GemmArgs p{};
       p.A = e->obuf; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.bias = L.proj.b;
       p.M = M; p.N = D; p.K = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = x; p.ldx = D;
@@ -437,6 +461,7 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
     f.A = e->hbuf; f.lda = D; f.W = L.fc1.w; f.ldw = L.fc1.ld; f.bias = L.fc1.b;
     f.M = M; f.N = L.ld_int; f.K = D; f.tiles_n = L.fc1.rows_pad / GEMM_BN; f.out = e->actbuf; f.ldo = L.ld_int;
     f.score_site = fused ? score_site : 0; f.tokens = e->tokens; f.slab = e->slab; f.slab_ld = L.ld_int;
+    f.group = rm.group; f.mpad = rm.mpad; f.n_img = n;
     f.group_m = 8;   // 8 x 8 tile patches per XCD: the 4.7 MB fc1 weight no longer thrashes the 4 MiB L2 (PMC: FETCH_SIZE / 3.7)
     // unfused pre-GELU scoring (models with < 128 tokens): the hook sees fc1's output, fc2 consumes the GELU
     // of it, so the epilogue also stores the pre-activation for the standalone L2 kernel to read.
@@ -450,14 +475,14 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
       if (fused) {
         ProfScope ps(e, SSP2_K_SCORE_FINISH);
         hipLaunchKernelGGL(score_norms_from_slab_kernel, dim3((L.ld_int + 255) / 256, n), dim3(256), 0, e->stream,
-                           e->slab, e->norms, n, e->tokens, L.ld_int, score_chain);
+                           e->slab, e->norms, n, rm, L.ld_int, score_chain);
         hipLaunchKernelGGL(score_colsum_kernel, dim3((L.ld_int + 255) / 256, n_groups), dim3(256), 0, e->stream, e->norms, row,
                            group_stride, n, grp, L.ld_int, score_chain);
         HIPCHK(hipGetLastError());
       } else {
         const bf16* seen = (score_site == SSP2_SCORE_PRE_GELU) ? e->prebuf : e->actbuf;
         ProfScope ps(e, SSP2_K_ACT_L2);
-        if ((rc = ssp2_act_l2_accum(e->stream, seen, 0, n, e->tokens, L.d_int, L.ld_int, score_chain, grp, e->norms, row, group_stride))) return rc;
+        if ((rc = act_l2_impl(e->stream, seen, 0, n, rm, L.d_int, L.ld_int, score_chain, grp, e->norms, row, group_stride))) return rc;
       }
     }
     GemmArgs o{};
@@ -469,11 +494,11 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
 }
 
 static int head_impl(ssp2_engine* e, const float* x, size_t in_stride, int n, float* logits_dev, int32_t* pred, const int64_t* labels,
-                     int64_t* correct) {
+                     int64_t* correct, RowMap gather = RowMap{0, 0, 0}) {
   int rc;
   if (!(e->misc_set[2] && e->misc_set[3] && e->head.w_set && e->head.b_set)) return fail(SSP2_ESTATE, "final norm / head weights not loaded");
   const int D = e->d.dim;
-  if ((rc = launch_ln(e, x, in_stride, e->lnf_g, e->lnf_b, e->cls_h, D, n, D))) return rc;
+  if ((rc = launch_ln(e, x, in_stride, e->lnf_g, e->lnf_b, e->cls_h, D, n, D, gather))) return rc;
   float* lg = logits_dev ? logits_dev : e->logits;
   GemmArgs g{};
   g.A = e->cls_h; g.lda = D; g.W = e->head.w; g.ldw = e->head.ld; g.bias = e->head.b;
@@ -488,11 +513,11 @@ static int head_impl(ssp2_engine* e, const float* x, size_t in_stride, int n, fl
   return 0;
 }
 
-int ssp2_head(ssp2_handle e, const float* x, int n, float* logits_dev, int32_t* pred, const int64_t* labels, int64_t* correct) {
+int ssp2_head(ssp2_handle e, const float* x, int n, int group, float* logits_dev, int32_t* pred, const int64_t* labels, int64_t* correct) {
   int rc;
-  if ((rc = check_n(e, n))) return rc;
+  if ((rc = check_n(e, n, group))) return rc;
   if (!x) return fail(SSP2_EINVAL, "null x");
-  return head_impl(e, x, (size_t)e->tokens * e->d.dim, n, logits_dev, pred, labels, correct);
+  return head_impl(e, x, (size_t)e->tokens * e->d.dim, n, logits_dev, pred, labels, correct, make_rowmap(e->tokens, n, group));
 }
 
 int ssp2_tail(ssp2_handle e, const float* x, int n, int attn_skip_last, float* logits_dev, int32_t* pred, const int64_t* labels,
@@ -518,7 +543,7 @@ int ssp2_tail(ssp2_handle e, const float* x, int n, int attn_skip_last, float* l
     q.A = e->h_cls; q.lda = D; q.W = L.qkv.w; q.ldw = L.qkv.ld; q.bias = L.qkv.b;
     q.M = n; q.N = D; q.K = D; q.tiles_n = (D + GEMM_BN - 1) / GEMM_BN; q.out = e->q_cls; q.ldo = D;
     if ((rc = launch_gemm<EPI_BF16>(e, q, SSP2_K_GEMM_QKV))) return rc;
-    if ((rc = launch_attn(e, n, true))) return rc;
+    if ((rc = launch_attn(e, n, RowMap{e->tokens, 0, 0}, true))) return rc;
     GemmArgs p{};
     p.A = e->o_cls; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.bias = L.proj.b;
     p.M = n; p.N = D; p.K = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = e->x_cls; p.ldx = D;
@@ -582,21 +607,7 @@ int ssp2_prune_ffn(ssp2_handle e, int layer, const int32_t* keep, int n_keep) {
 
 int ssp2_act_l2_accum(void* stream, const void* act, int dtype, int n, int tokens, int d, int ld, int chain, int group,
                       float* norms_ws, float* out, size_t out_stride) {
-  if (!act || !norms_ws || !out) return fail(SSP2_EINVAL, "null device pointer");
-  if (n <= 0 || tokens <= 0 || d <= 0 || ld < d || (ld % 8)) return fail(SSP2_EINVAL, "bad shape n=%d tokens=%d d=%d ld=%d (ld multiple of 8, >= d)", n, tokens, d, ld);
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid((ld + 511) / 512, n), blk(256);
-  if (dtype == 0)
-    hipLaunchKernelGGL(act_l2_norms_kernel<bf16>, grid, blk, 0, s, (const bf16*)act, norms_ws, tokens, ld, chain);
-  else if (dtype == 1)
-    hipLaunchKernelGGL(act_l2_norms_kernel<float>, grid, blk, 0, s, (const float*)act, norms_ws, tokens, ld, chain);
-  else
-    return fail(SSP2_EINVAL, "dtype %d (0 = bf16, 1 = f32)", dtype);
-  const int grp = (group <= 0 || group > n) ? n : group;
-  hipLaunchKernelGGL(score_colsum_kernel, dim3((ld + 255) / 256, (n + grp - 1) / grp), dim3(256), 0, s, norms_ws, out, out_stride, n, grp, ld,
-                     chain);
-  HIPCHK(hipGetLastError());
-  return 0;
+  return act_l2_impl(stream, act, dtype, n, RowMap{tokens, 0, 0}, d, ld, chain, group, norms_ws, out, out_stride);
 }
 
 int ssp2_profile_begin(ssp2_handle e, int klass) {
@@ -709,3 +720,24 @@ int ssp2_preproc_run(ssp2_preproc_handle p, void* stream, const uint8_t* img_dev
 }
 
 }  // extern "C"
+
+static int act_l2_impl(void* stream, const void* act, int dtype, int n, RowMap rm, int d, int ld, int chain, int group,
+                       float* norms_ws, float* out, size_t out_stride) {
+  const int tokens = rm.tokens;
+  if (!act || !norms_ws || !out) return fail(SSP2_EINVAL, "null device pointer");
+  if (n <= 0 || tokens <= 0 || d <= 0 || ld < d || (ld % 8)) return fail(SSP2_EINVAL, "bad shape n=%d tokens=%d d=%d ld=%d (ld multiple of 8, >= d)", n, tokens, d, ld);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((ld + 511) / 512, n), blk(256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(act_l2_norms_kernel<bf16>, grid, blk, 0, s, (const bf16*)act, norms_ws, rm, ld, chain);
+  else if (dtype == 1)
+    hipLaunchKernelGGL(act_l2_norms_kernel<float>, grid, blk, 0, s, (const float*)act, norms_ws, rm, ld, chain);
+  else
+    return fail(SSP2_EINVAL, "dtype %d (0 = bf16, 1 = f32)", dtype);
+  const int grp = (group <= 0 || group > n) ? n : group;
+  hipLaunchKernelGGL(score_colsum_kernel, dim3((ld + 255) / 256, (n + grp - 1) / grp), dim3(256), 0, s, norms_ws, out, out_stride, n, grp, ld,
+                     chain);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+

@@ -47,6 +47,7 @@ struct GemmArgs {
   // EPI_FC1
   int score_site;             // 0 none, 1 pre-GELU, 2 post-GELU
   int tokens;                 // tokens per sample (>= GEMM_BM when score_site != 0)
+  int group, mpad, n_img;     // slab layout of the rows (RowMap); group == 0: contiguous
   float* slab; int slab_ld;   // [tiles_m][2][slab_ld]
   // EPI_PATCH
   const float* pos; int patches;
@@ -260,8 +261,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
   if (EPI == EPI_BF16 || EPI == EPI_FC1) {
     char* stg = smem + wave * 8192;          // wave-private [64][64] bf16
     float ssq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    // first row (inside the 128-row tile) that belongs to the NEXT sample; rows >= M never count
-    const int bnd = (EPI == EPI_FC1 && SCORE) ? (m0 / g.tokens + 1) * g.tokens - m0 : (1 << 30);
+    // Row coordinates inside this tile's slab (contiguous layout = one slab): ml0 = first row of the tile,
+    // rows_s = valid rows of the slab, bnd = first row (inside the tile) that belongs to the NEXT sample.
+    int bnd = 1 << 30, row_lim = g.M - m0;       // rows of the tile at or past row_lim never count
+    if (EPI == EPI_FC1 && SCORE) {
+      int ml0 = m0;
+      if (g.group > 0) {
+        const int sb = m0 / g.mpad;
+        ml0 = m0 - sb * g.mpad;
+        const int imgs = min(g.group, g.n_img - sb * g.group);
+        row_lim = imgs * g.tokens - ml0;
+      }
+      bnd = (ml0 / g.tokens + 1) * g.tokens - ml0;
+    }
     const bool keep_pre = (EPI == EPI_FC1) && g.out2 != nullptr;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
       for (int a = 0; a < 2; ++a) {
         // does this 32-row sub-tile lie wholly inside one sample and inside M?  (wave-uniform)
         const int rb = wr * 64 + a * 32;
-        const bool plain = (rb + 32 <= bnd || rb >= bnd) && (m0 + rb + 32 <= g.M);
+        const bool plain = (rb + 32 <= bnd || rb >= bnd) && (rb + 32 <= row_lim);
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
                 s0 = fmaf(sv.x, sv.x, s0); s0 = fmaf(sv.y, sv.y, s0);
               } else {                                   // sub-tile straddles two samples or the end of M
                 const int r0 = wr * 64 + rw;
-                const float q0 = (m0 + r0 < g.M) ? sv.x * sv.x : 0.f, q1 = (m0 + r0 + 1 < g.M) ? sv.y * sv.y : 0.f;
+                const float q0 = (r0 < row_lim) ? sv.x * sv.x : 0.f, q1 = (r0 + 1 < row_lim) ? sv.y * sv.y : 0.f;
                 if (r0 < bnd) s0 += q0; else s1 += q0;
                 if (r0 + 1 < bnd) s0 += q1; else s1 += q1;
               }
@@ -368,7 +380,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
         xin[it] = *(const f32x4*)dst[it];
       } else {
         const int img = mc / g.patches, p = mc - img * g.patches;
-        dst[it] = g.x + ((size_t)img * (g.patches + 1) + 1 + p) * g.ldx + col0 + c;
+        const RowMap rm{g.patches + 1, g.group, g.mpad};
+        dst[it] = g.x + (size_t)(row_of(rm, img) + 1 + p) * g.ldx + col0 + c;
         xin[it] = *(const f32x4*)(g.pos + (size_t)(1 + p) * g.ldx + col0 + c);
       }
     }

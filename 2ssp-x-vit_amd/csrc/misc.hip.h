@@ -35,11 +35,11 @@ __global__ void im2col_patch_kernel(const float* __restrict__ px, bf16* __restri
 
 // x[img*N + 0] = cls + pos[0]   (fp32; the concat promotes to fp32 under autocast)
 __global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
-                               int n, int tokens, int dim) {
+                               int n, RowMap rm, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n * dim) {
     const int im = i / dim, d = i - im * dim;
-    x[(size_t)im * tokens * dim + d] = cls[d] + pos[d];
+    x[(size_t)row_of(rm, im) * dim + d] = cls[d] + pos[d];
   }
 }
 
@@ -52,11 +52,12 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, size_t in_stride,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16* __restrict__ y,
-                                                            int out_ld, int rows, int D, float eps) {
+                                                            int out_ld, int rows, int D, float eps, RowMap gather) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const f32x4* xr = (const f32x4*)(x + (size_t)row * in_stride);
+  // gather.tokens > 0: output row r is the CLS row of image r (slab layout aware); else input row r*in_stride
+  const f32x4* xr = (const f32x4*)(gather.tokens > 0 ? x + (size_t)row_of(gather, row) * D : x + (size_t)row * in_stride);
   const int nv = D >> 2;                      // float4 chunks in the row
   f32x4 v[MAXV];
   float s = 0.f;
@@ -95,14 +96,19 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
 //   slab [tiles_m][2][ld]: tile t covers rows [128t, 128t+128); segment 0 = rows of sample floor(128t/N),
 //   segment 1 = rows of the following sample.  norms[s][j] = sqrt(sum of the segments that belong to s).
 __global__ void score_norms_from_slab_kernel(const float* __restrict__ slab, float* __restrict__ norms, int n,
-                                             int tokens, int ld, int chain) {
+                                             RowMap rm, int ld, int chain) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
   if (j >= ld) return;
-  const int t0 = (s * tokens) / 128, t1 = ((s + 1) * tokens - 1) / 128;
+  const int tokens = rm.tokens;
+  const long r0 = row_of(rm, s);                                  // first row of the sample
+  const long slab0 = rm.group > 0 ? (long)(s / rm.group) * rm.mpad : 0;   // first row of its slab (multiple of 128)
+  const int sl = rm.group > 0 ? s % rm.group : s;                 // index of the sample inside its slab
+  const int t0 = (int)(r0 / 128), t1 = (int)((r0 + tokens - 1) / 128);
   float acc = 0.f;
   for (int t = t0; t <= t1; ++t) {
-    const int seg = ((t * 128) / tokens == s) ? 0 : 1;
+    const int first = (int)(((long)t * 128 - slab0) / tokens);    // slab-local sample that owns the tile's first row
+    const int seg = (first == sl) ? 0 : 1;
     acc += slab[((size_t)t * 2 + seg) * ld + j];
   }
   float nrm = sqrtf(acc);
@@ -145,7 +151,8 @@ __device__ __forceinline__ void load8<float>(const float* p, float (&f)[8]) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__ act, float* __restrict__ norms,
-                                                          int tokens, int ld, int chain) {
+                                                          RowMap rm, int ld, int chain) {
+  const int tokens = rm.tokens;
   __shared__ float red[4][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = blockIdx.y;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
   if (ok) {
-    const T* base = act + (size_t)s * tokens * ld + col;
+    const T* base = act + (size_t)row_of(rm, s) * ld + col;
     int t = wave;
     for (; t + 12 < tokens; t += 16) {
       float f0[8], f1[8], f2[8], f3[8];

@@ -17,7 +17,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 SYMBOLS = [
     "ssp2_abi_version", "ssp2_last_error", "ssp2_create", "ssp2_destroy", "ssp2_set_stream", "ssp2_load_tensor",
     "ssp2_embed", "ssp2_layers", "ssp2_head", "ssp2_tail", "ssp2_prune_ffn", "ssp2_drop_attention", "ssp2_d_int", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
-    "ssp2_tokens", "ssp2_workspace_bytes", "ssp2_preproc_create", "ssp2_preproc_run", "ssp2_preproc_destroy",
+    "ssp2_tokens", "ssp2_rows", "ssp2_workspace_bytes", "ssp2_preproc_create", "ssp2_preproc_run", "ssp2_preproc_destroy",
 ]
 
 T_KINDS = ["patch_w", "patch_b", "cls", "pos", "ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
@@ -101,9 +101,11 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_destroy.argtypes = [vp]
     lib.ssp2_set_stream.argtypes = [vp, vp]
     lib.ssp2_load_tensor.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.c_size_t]
-    lib.ssp2_embed.argtypes = [vp, vp, i32, vp]
+    lib.ssp2_embed.argtypes = [vp, vp, i32, vp, i32]
+    lib.ssp2_rows.argtypes = [vp, i32, i32]
+    lib.ssp2_rows.restype = C.c_long
     lib.ssp2_layers.argtypes = [vp, vp, i32, i32, i32, C.POINTER(C.c_uint8), i32, i32, i32, vp, i32]
-    lib.ssp2_head.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+    lib.ssp2_head.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     lib.ssp2_tail.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
     lib.ssp2_prune_ffn.argtypes = [vp, i32, C.POINTER(C.c_int32), i32]
     lib.ssp2_drop_attention.argtypes = [vp, i32]
@@ -119,7 +121,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_preproc_destroy.argtypes = [vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("ssp2_last_error", "ssp2_workspace_bytes"):
+        if name not in ("ssp2_last_error", "ssp2_workspace_bytes", "ssp2_rows"):
             fn.restype = i32
     _lib = lib
     return lib

@@ -27,6 +27,7 @@ def iter_limited(dataloader: Iterable, limit: Optional[int], progress: bool, des
 
 
 DEFAULT_CHUNK_IMAGES = int(os.environ.get("SSP2_CHUNK_IMAGES", "256"))
+MAX_SLABS = 16          # the engine's workspace carries slack for 16 padded slabs per call (csrc/engine.hip rows_cap)
 
 
 def _resolve(engine, min_images: int):
@@ -41,8 +42,8 @@ class _Chunker:
     must all have the size of the first one, except the last (a ragged final batch closes the chunk), so that group
     g of the chunk is exactly dataloader batch g (needed for the per-batch score sums)."""
 
-    def __init__(self, capacity: int, device):
-        self.capacity, self.device = capacity, device
+    def __init__(self, capacity: int, device, max_batches: int = 1 << 30):
+        self.capacity, self.device, self.max_batches = capacity, device, max_batches
         self.items = []          # (global batch index, pixels on device, labels or None)
         self.count = 0
 
@@ -50,7 +51,8 @@ class _Chunker:
         if not self.items:
             return False
         g = self.items[0][1].size(0)
-        return n > g or self.count + n > self.capacity or self.items[-1][1].size(0) < g
+        return (n > g or self.count + n > self.capacity or self.items[-1][1].size(0) < g
+                or len(self.items) >= self.max_batches)
 
     def add(self, idx, px, labels=None):
         self.items.append((idx, px.to(self.device, torch.float32, non_blocking=True),
@@ -72,12 +74,12 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
                   chunk_images: Optional[int] = None) -> List[torch.Tensor]:
     """Reference src/vit_pruning.py:111-201.  `engine`: VitEngine or callable(min_images) -> VitEngine.
 
-    Default: ONE dataloader batch per forward.  A sample's sum of squares is folded per 128-row GEMM tile, so its
-    fp32 rounding depends on where the sample sits in the launch; one batch per launch pins that position and makes
-    the scores bit-identical for every world size.  `chunk_images` > batch size packs several batches per launch
-    (faster; scores then move by ~1e-7 relative with the packing)."""
+    Several dataloader batches share one forward (`chunk_images`, default SSP2_CHUNK_IMAGES).  A sample's sum of
+    squares is folded per 128-row GEMM tile, so its fp32 rounding depends on where the sample sits relative to the
+    tile grid; every batch is therefore laid out as its own 256-row-aligned slab (ssp2_rows / RowMap), which pins
+    that position: scores are bit-identical for every packing and every world size."""
     rank, ws = _dist.world(process_group)
-    chunk_images = chunk_images or 0
+    chunk_images = DEFAULT_CHUNK_IMAGES if chunk_images is None else chunk_images
     local: List[Tuple[int, torch.Tensor]] = []
     n_samples = n_batches = 0
     eng = None
@@ -99,7 +101,7 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
             if ch is not None and ch.items:
                 flush()
             eng = _resolve(engine, max(chunk_images, n))
-            ch = _Chunker(min(eng.max_images, max(chunk_images, n)), eng.device)
+            ch = _Chunker(min(eng.max_images, max(chunk_images, n)), eng.device, max_batches=MAX_SLABS)
         if ch.full_for(n):
             flush()
         ch.add(i, px)
@@ -132,24 +134,52 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
 
 
 def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images):
-    """Yields (engine, pixels, labels) chunks of the batches this rank owns."""
+    """Yields (engine, pixels, labels) chunks of EXACTLY `chunk_images` images (the last one may be short) cut from
+    the concatenation of the batches this rank owns.  Evaluation results are integer counts, so where the cuts fall
+    cannot change them; the chunk size is chosen for the GEMM tile grid (see best_eval_chunk)."""
     eng = None
-    ch = None
+    px_buf, lb_buf, count = [], [], 0
+
+    def cut(k):
+        nonlocal px_buf, lb_buf, count
+        px = px_buf[0] if len(px_buf) == 1 else torch.cat(px_buf, 0)
+        lb = lb_buf[0] if len(lb_buf) == 1 else torch.cat(lb_buf, 0)
+        out = (eng, px[:k], lb[:k])
+        px_buf, lb_buf, count = ([px[k:]], [lb[k:]], count - k) if k < count else ([], [], 0)
+        return out
+
     for i, batch in iter_limited(dataloader, limit, progress, desc):
         if not _dist.owns(i, rank, ws):
             continue
         px, labels = batch["pixel_values"], batch["labels"]
-        n = int(px.size(0))
-        if eng is None or (callable(engine) and n > eng.max_images):
-            if ch is not None and ch.items:
-                yield (eng,) + ch.take()[2:]
-            eng = _resolve(engine, max(chunk_images, n))
-            ch = _Chunker(min(eng.max_images, max(chunk_images, n)), eng.device)
-        if ch.full_for(n):
-            yield (eng,) + ch.take()[2:]
-        ch.add(i, px, labels)
-    if ch is not None and ch.items:
-        yield (eng,) + ch.take()[2:]
+        if eng is None:
+            eng = _resolve(engine, max(chunk_images, int(px.size(0))))
+        cap = min(eng.max_images, chunk_images) if chunk_images > 0 else min(eng.max_images, int(px.size(0)))
+        px_buf.append(px.to(eng.device, torch.float32, non_blocking=True))
+        lb_buf.append(labels.to(eng.device, torch.int64, non_blocking=True))
+        count += int(px.size(0))
+        while count >= cap:
+            yield cut(cap)
+    if count:
+        yield cut(count)
+
+
+def best_eval_chunk(tokens: int, cap: int, n_cu: int = 256, tile_m: int = 256, col_tiles=(3, 3, 9, 12)) -> int:
+    """Images per evaluation forward that waste the fewest CU-rounds of the persistent 256x256 GEMMs: the four
+    projections of a block have col_tiles column tiles each (B/16: proj 3, fc2 3, QKV 9, fc1 12) and
+    ceil(n*tokens/256) row tiles; a launch of T tiles occupies ceil(T / n_cu) rounds of the chip.  Among the chunk
+    sizes whose utilisation is within 2 % of the best, the SMALLEST wins (its activations stay in the 256 MiB
+    Infinity Cache between producer and consumer kernels)."""
+    best, scored = None, []
+    for n in range(min(16, cap), cap + 1):
+        rows = -(-n * tokens // tile_m)
+        used = sum(rows * c for c in col_tiles)
+        paid = sum(-(-rows * c // n_cu) * n_cu for c in col_tiles)
+        scored.append((used / paid * (n * tokens) / (rows * tile_m), n))
+    if not scored:
+        return cap
+    top = max(u for u, _ in scored)
+    return min(n for u, n in scored if u >= top - 0.02)
 
 
 @torch.no_grad()

@@ -102,21 +102,24 @@ class VitEngine:
             return None
         return (C.c_uint8 * self.depth)(*flags)
 
-    def new_x(self, n: int) -> torch.Tensor:
-        return torch.empty(n * self.tokens, self.dim, dtype=torch.float32, device=self.device)
+    def rows(self, n: int, group: int = 0) -> int:
+        return int(self.lib.ssp2_rows(self.h, n, int(group)))
+
+    def new_x(self, n: int, group: int = 0) -> torch.Tensor:
+        return torch.empty(self.rows(n, group), self.dim, dtype=torch.float32, device=self.device)
 
     def new_scores(self, groups: int = 1) -> torch.Tensor:
         return torch.zeros(groups, self.depth, self.score_ld, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ the four device entry points
-    def embed(self, pixels: torch.Tensor, x: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def embed(self, pixels: torch.Tensor, x: Optional[torch.Tensor] = None, group: int = 0) -> torch.Tensor:
         if pixels.dim() != 4 or pixels.shape[1] != 3 or pixels.shape[2] != self.img or pixels.shape[3] != self.img:
             raise ValueError(f"pixel_values must be [n,3,{self.img},{self.img}], got {tuple(pixels.shape)}")
         px = pixels.to(self.device, torch.float32, non_blocking=True).contiguous()
         n = px.shape[0]
-        x = self.new_x(n) if x is None else x
+        x = self.new_x(n, group) if x is None else x
         self._bind_stream()
-        check(self.lib.ssp2_embed(self.h, _ptr(px), n, _ptr(x)))
+        check(self.lib.ssp2_embed(self.h, _ptr(px), n, _ptr(x), int(group)))
         return x
 
     def layers(self, x: torch.Tensor, n: int, l_begin: int = 0, l_end: Optional[int] = None,
@@ -130,11 +133,11 @@ class VitEngine:
             batch_scores = self.new_scores((n + grp - 1) // grp)
         self._bind_stream()
         check(self.lib.ssp2_layers(self.h, _ptr(x), n, l_begin, l_end, self._skip_array(attn_skip), site,
-                                   SCORE_CHAIN[score_chain], grp, _ptr(batch_scores if site else None), self.score_ld))
+                                   SCORE_CHAIN[score_chain], int(score_group), _ptr(batch_scores if site else None), self.score_ld))
         return batch_scores if site else None
 
     def head(self, x: torch.Tensor, n: int, labels: Optional[torch.Tensor] = None,
-             correct: Optional[torch.Tensor] = None, want_logits: bool = False, want_pred: bool = False):
+             correct: Optional[torch.Tensor] = None, want_logits: bool = False, want_pred: bool = False, group: int = 0):
         logits = torch.empty(n, self.classes, dtype=torch.float32, device=self.device) if want_logits else None
         pred = torch.empty(n, dtype=torch.int32, device=self.device) if want_pred else None
         if labels is not None:
@@ -142,7 +145,7 @@ class VitEngine:
             if correct is None:
                 correct = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._bind_stream()
-        check(self.lib.ssp2_head(self.h, _ptr(x), n, _ptr(logits), _ptr(pred), _ptr(labels),
+        check(self.lib.ssp2_head(self.h, _ptr(x), n, int(group), _ptr(logits), _ptr(pred), _ptr(labels),
                                  _ptr(correct if labels is not None else None)))
         return logits, pred, correct
 
@@ -184,7 +187,7 @@ class VitEngine:
         n = pixels.shape[0]
         if n > self.max_images:
             raise Ssp2Error(f"chunk of {n} images exceeds engine capacity {self.max_images}")
-        x = self.embed(pixels)
+        x = self.embed(pixels, group=group)             # slab layout: one 256-row-aligned slab per batch
         return self.layers(x, n, 0, self.depth, None, score_site, score_chain, None, group)
 
     def forward_logits(self, pixels: torch.Tensor, attn_skip: Optional[Sequence[int]] = None) -> torch.Tensor:

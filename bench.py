@@ -102,7 +102,8 @@ def main():
     ap.add_argument("--calib", type=int, default=512, help="calibration images per GPU")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--eval-batches", type=int, default=5)
-    ap.add_argument("--calib-chunk", type=int, default=0, help="images per stage-1 forward (0 = one batch; see core.stage1_scores)")
+    ap.add_argument("--calib-chunk", type=int, default=512, help="images per stage-1 forward (0 = one batch; see core.stage1_scores)")
+    ap.add_argument("--eval-chunk", type=int, default=0, help="images per search forward (0 = all eval images of the rank)")
     ap.add_argument("--target", type=float, default=0.375)
     ap.add_argument("--cpu-sample", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -154,7 +155,7 @@ def main():
         imps = core.stage1_scores(eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
                                   chunk_images=args.calib_chunk)
         base, cand, total = core.depth_search_counts(eng, eval_loader, depth, batch_limit=None, process_group=pg,
-                                                     chunk_images=n_eval)
+                                                     chunk_images=args.eval_chunk or n_eval)
         impact = torch.tensor(core.impacts_from_counts(base, cand, total), dtype=torch.float32)
         masks = []
         t = plan.per_block_neurons_to_prune

@@ -77,12 +77,19 @@ int ssp2_set_stream(ssp2_handle h, void* hip_stream);
  * parameters / cls / pos stay fp32.  Synchronous. */
 int ssp2_load_tensor(ssp2_handle h, int kind, int layer, const float* host, size_t numel);
 
-/* a3 (patch-embed conv k=s=p + cls + pos):  pixels_dev f32 NCHW [n,3,img,img]  ->  x_dev f32 [n*N, dim] */
-int ssp2_embed(ssp2_handle h, const float* pixels_dev, int n, float* x_dev);
+/* Row layout of the token matrix x.  group <= 0 or >= n: images contiguous, ssp2_rows = n*N.  0 < group < n: SLABS of
+ * `group` images (one dataloader batch each), every slab padded to a multiple of 256 rows — a sample then sits at the
+ * same offset inside its slab whichever call it is part of, so per-tile partial sums (hence stage-1 scores) do not
+ * depend on how many batches share a call.  ssp2_embed / ssp2_layers / ssp2_head of one forward take the same group. */
+long ssp2_rows(ssp2_handle h, int n, int group);
+
+/* a3 (patch-embed conv k=s=p + cls + pos):  pixels_dev f32 NCHW [n,3,img,img]  ->  x_dev f32 [ssp2_rows(n,group), dim] */
+int ssp2_embed(ssp2_handle h, const float* pixels_dev, int n, float* x_dev, int group);
 
 /* a3/a2/a6: run encoder blocks [l_begin, l_end) in place on the residual stream x_dev [n*N, dim].
  *   attn_skip      host bytes [depth] or NULL; attn_skip[l]!=0 == the reference's zero-output attention
  *                  bypass (src/vit_pruning.py:416-429): the block computes x <- x + MLP(LN2(x)) only.
+ *   score_group    the row layout group of x (see ssp2_rows) AND the scoring group:
  *   score_site     SSP2_SCORE_*: if not NONE, the call's n samples are cut into groups of score_group
  *                  consecutive samples (= the reference dataloader's batches; the last group may be short) and
  *                  batch_scores_dev[g][l][:] receives sum_{s in group g} || act_l[s,:,j] ||_2 (the hook body,
@@ -96,13 +103,14 @@ int ssp2_layers(ssp2_handle h, float* x_dev, int n, int l_begin, int l_end, cons
 /* a3 tail + a4: final LayerNorm on the CLS rows, classifier, first-max-index argmax (torch.argmax rule),
  * comparison with labels.  Any of logits_dev [n,classes] f32, pred_dev [n] i32, labels_dev [n] i64 +
  * correct_dev [1] i64 (ACCUMULATED into, caller zeroes) may be NULL. */
-int ssp2_head(ssp2_handle h, const float* x_dev, int n, float* logits_dev, int32_t* pred_dev,
+int ssp2_head(ssp2_handle h, const float* x_dev, int n, int group, float* logits_dev, int32_t* pred_dev,
               const int64_t* labels_dev, int64_t* correct_dev);
 
 /* Evaluation tail (a4, every pass of the a5 search): the LAST encoder block followed by the head, computed for
  * the CLS rows only — keys/values are formed for every token, but the query, the attention output, the
  * out-projection and the whole MLP run on n rows instead of n*N.  Bit-identical to
- * ssp2_layers(x, depth-1, depth) + ssp2_head(x) (same per-row instruction sequences); x_dev is NOT modified.
+ * ssp2_layers(x, depth-1, depth) + ssp2_head(x) (same per-row instruction sequences); x_dev is NOT modified and
+ * must be in the contiguous layout (group 0).
  * attn_skip_last != 0 bypasses the last block's attention. */
 int ssp2_tail(ssp2_handle h, const float* x_dev, int n, int attn_skip_last, float* logits_dev, int32_t* pred_dev,
               const int64_t* labels_dev, int64_t* correct_dev);

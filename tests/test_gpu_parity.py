@@ -278,9 +278,10 @@ def test_copy_mode_selection_and_width_prune_end_to_end(gpu):
     vp.release_engines()
 
 
-def test_eval_chunking_is_exact_and_stage1_packing_is_close(gpu):
+def test_eval_chunking_is_exact_and_stage1_packing_is_bit_identical(gpu):
     """Stage-2 / top-1 counts are integers: packing several dataloader batches into one forward must not change
-    them.  Stage-1 packing (opt-in) keeps per-batch groups and may move scores only at fp32 rounding level."""
+    them.  Stage-1 packing lays every batch out as its own 256-row-aligned slab (ssp2_rows), so a sample meets the
+    same GEMM tiles whichever launch it is part of: scores are BIT-IDENTICAL to one batch per forward."""
     from oracle.vit_modules import build_from_flat
     from ssp2vit import core, vit_pruning as vp
     from ssp2vit.engine import VitEngine
@@ -297,15 +298,45 @@ def test_eval_chunking_is_exact_and_stage1_packing_is_close(gpu):
     assert one == packed and one[2] == 29
     assert core.top1_counts(eng, batches, chunk_images=8) == core.top1_counts(eng, batches, chunk_images=32)
     d_ints = [768] * 12
-    a = core.stage1_scores(eng, batches, d_ints, "pre_gelu")                       # one batch per forward
+    a = core.stage1_scores(eng, batches, d_ints, "pre_gelu", chunk_images=0)       # one batch per forward
     b = core.stage1_scores(eng, batches, d_ints, "pre_gelu", chunk_images=32)      # 4 batches in one forward
-    for x, y in zip(a, b):
-        assert torch.allclose(x, y, rtol=1e-5, atol=0)
+    b2 = core.stage1_scores(eng, batches, d_ints, "pre_gelu", chunk_images=16)     # 2 + 2 batches
+    for x, y, z in zip(a, b, b2):
+        assert torch.equal(x, y) and torch.equal(x, z)
     c = core.stage1_scores(eng, batches, d_ints, "pre_gelu", score_chain="bf16_ref", chunk_images=32)
-    d = core.stage1_scores(eng, batches, d_ints, "pre_gelu", score_chain="bf16_ref")
+    d = core.stage1_scores(eng, batches, d_ints, "pre_gelu", score_chain="bf16_ref", chunk_images=8)
     for x, y in zip(c, d):
-        ulp = (x.view(torch.int16).int() - y.view(torch.int16).int()).abs()
-        assert int(ulp.max()) <= 1
+        assert torch.equal(x, y)
+    # post-GELU site and the slab-aware head: logits of a slab-layout forward equal the contiguous forward's
+    e = core.stage1_scores(eng, batches, d_ints, "post_gelu", chunk_images=8)
+    f = core.stage1_scores(eng, batches, d_ints, "post_gelu", chunk_images=32)
+    for x, y in zip(e, f):
+        assert torch.equal(x, y)
+    px = torch.cat([bt["pixel_values"] for bt in batches[:3]], 0).cuda()
+    xs = eng.embed(px, group=8); eng.layers(xs, 24, score_group=8)
+    xc = eng.embed(px); eng.layers(xc, 24)
+    ls = eng.head(xs, 24, want_logits=True, group=8)[0]
+    lc = eng.head(xc, 24, want_logits=True)[0]
+    assert torch.equal(ls, lc)
+
+
+def test_slab_layout_small_token_model_unfused_path(gpu):
+    """The 5-token smoke geometry scores through the standalone L2 kernel (no fused epilogue below 128 tokens); the
+    slab layout must give the same bits there too, including a ragged last batch."""
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    w, batches, _ = load_tiny_golden("timm")
+    d_ints = [int(w[f"fc1_w.{i}"].shape[0]) for i in range(int(w["depth"]))]
+    g = torch.Generator().manual_seed(3)
+    n0 = batches[0]["pixel_values"].shape[0]
+    more = [{"pixel_values": torch.randn(n, *batches[0]["pixel_values"].shape[1:], generator=g)} for n in (n0, n0, n0 - 3)]
+    allb = [{"pixel_values": b["pixel_values"]} for b in batches] + more
+    eng = VitEngine(w, max_images=64)
+    for site in ("pre_gelu", "post_gelu"):
+        a = core.stage1_scores(eng, allb, d_ints, site, chunk_images=n0)
+        b = core.stage1_scores(eng, allb, d_ints, site, chunk_images=64)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("cfg", ["vit_tiny_patch16_224", "vit_test_patch16_32"])
