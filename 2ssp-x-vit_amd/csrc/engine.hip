@@ -153,11 +153,11 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
   g.tiles_n = (g.N + 255) / 256;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<8>::LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS));
     attr_done = true;
   }
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
-  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, 8>), dim3(std::min(g.tiles_m * g.tiles_n, e->n_cu)), dim3(512), G256<8>::LDS, e->stream, g);
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI>), dim3(std::min(g.tiles_m * g.tiles_n, e->n_cu)), dim3(512), G256::LDS, e->stream, g);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -1,112 +1,114 @@
-// Large-tile variant of the bf16 MFMA GEMM for the big-M projections (QKV, attention out-proj, fc2):
-// 256 x 256 x 64 tiles, 8 or 16 waves, ONE persistent workgroup per CU.
+// Large-tile bf16 MFMA GEMM for the big-M projections (QKV, attention out-proj, fc1 of evaluation passes, fc2):
+// 256 x 256 x 64 tiles, 8 waves (2 along M x 4 along N, 128 x 64 per wave), ONE persistent workgroup per CU that
+// walks tiles wg, wg+G, wg+2G, ...  Results are bit-identical to gemm_bf16_kernel (same K order, same rounding
+// points); csrc/tools/gemm_bench.hip checks that on every run.
 //
-// Why a second kernel: in the 128x128 kernel every v_mfma_f32_32x32x16 (32 cycles of matrix pipe) is accompanied by
-// 0.5 LDS-DMA issues (~60 cycles each) and 1.0 ds_read_b128 (~23 cycles each) in the wave's own instruction stream,
-// so two waves per SIMD cannot keep the matrix pipe busy (measured with s_memtime stamps: 1665 cycles per K-tile for
-// 512 cycles of MFMA per wave).  A 256 x 256 tile with 128 x 64 per wave quarters the DMA issues per MFMA (0.125) and
-// cuts the fragment reads to 0.75; 256 x 128 (64 x 64 per wave) keeps more tiles in flight for N = 768 and affords a
-// three-deep ring.
+// LDS (all 160 KiB, one array):   A0 | A1 | B0 | B1 | A2     32 KiB each
+//   main loop   asymmetric ring as in gemm.hip.h: the A panel (streams from HBM / Infinity Cache) is three K-tiles
+//               deep, the weight panel (L2-resident) two.  Per K-tile a wave issues [B(kt+1) x4, A(kt+2) x4] by
+//               16-byte LDS-DMA and the K-tile boundary is ONE counted `s_waitcnt vmcnt(4)` + raw s_barrier, so
+//               A(kt+2) stays in flight across the barrier (the two-slot ring of round 1 waited ~420 cycles per
+//               K-tile for a drain to vmcnt(0)).
+//   tile change right after the last K-tile's barrier the NEXT tile's B(0), A(0), A(1) go out into B0, A0, A1; the
+//               epilogue then runs out of B1 | A2 (64 KiB = 8 KiB per wave, wave-private, no barrier inside).
+//               vmcnt counts loads, stores and LDS-DMA together in issue order, so the next main loop starts behind
+//               a counted wait that leaves only the epilogue's LAST stores in flight — nothing is ever drained to
+//               zero between two main loops (full tiles; an edge tile takes the conservative vmcnt(0) path).
 //
-//   NW =  8: waves 2(M) x 4(N), wave tile 128 x 64 (0.75 fragment reads per MFMA), two waves per SIMD
-//   NW = 16: waves 4(M) x 4(N), wave tile  64 x 64 (1.0 reads per MFMA), FOUR waves per SIMD (<= 128 VGPRs) — more
-//            waves to cover each other's DMA-issue / LDS-read stalls at the price of LDS bandwidth
-//   LDS ring 2 x 64 KiB (prefetch distance 1 tile).
-//
-// Staging, swizzle, fragment layout and the LDS-staged vector epilogues are those of gemm.hip.h.
+// Epilogue: the MFMA operands are swapped (acc = W_frag x A_frag), so a lane owns ONE output row and FOUR
+// consecutive columns per register quad.  Against the row-of-4-rows layout of the plain order this makes the bias
+// add and the bf16 conversion packed, replaces 16 two-byte LDS stores per 32x32 block by 4 eight-byte ones, and —
+// for the residual epilogue — lets the fp32 x tile ride the LDS-DMA engine: x is DMAed into the wave's staging
+// buffer (double-buffered 32x32 blocks, swizzled on the source address), updated in place from the accumulators,
+// and leaves as whole 128-byte row segments.  No VGPR ever waits for an x load.
 #pragma once
 #include "gemm.hip.h"
 #ifndef STAMP
 #define STAMP(slot) do {} while (0)
 #endif
 #ifdef GEMM_STAMPS
+#define TSTAMP(slot) do { if (tiles_done == 3) STAMP(slot); } while (0)
 #define RSTAMP(slot) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g.stamps[(size_t)blockIdx.x * 64 + (slot)] = t_; } } while (0)
 #else
+#define TSTAMP(slot) do {} while (0)
 #define RSTAMP(slot) do {} while (0)
 #endif
 
-template <int NW> struct G256 {
-  static constexpr int BM = 256, BN = 256;
-  static constexpr int WM = NW == 8 ? 2 : 4;            // waves along M
-  static constexpr int WN = 4;                          // waves along N
-  static constexpr int TM = BM / WM / 32;               // 32x32 MFMA tiles per wave along M (4 or 2)
-  static constexpr int TN = 2;
-  static constexpr int A_BYTES = BM * 128;              // 256 rows x 64 bf16
-  static constexpr int B_BYTES = BN * 128;
-  static constexpr int STAGE = A_BYTES + B_BYTES;       // 65536
-  static constexpr int LDS = 2 * STAGE;                 // 131072
-  static constexpr int GA = BM / 8 / NW;                // LDS-DMA pieces per wave per stage (A): 4 / 2
-  static constexpr int GB = BN / 8 / NW;
-  static constexpr int STG = STAGE / NW;                // wave-private epilogue staging bytes inside slot 1
-  static constexpr int ROWS16 = STG / 128;              // bf16 staging rows per pass (64 / 32)
-  static constexpr int ROWS32 = STG / 256;              // fp32 staging rows per pass (32 / 16)
+struct G256 {
+  static constexpr int BM = 256, BN = 256, NW = 8;
+  static constexpr int TM = 4, TN = 2;                  // 32x32 MFMA tiles per wave along M / N
+  static constexpr int SLOT = 32768;                    // 256 rows x 64 bf16
+  static constexpr int A0 = 0, A1 = SLOT, B0 = 2 * SLOT, B1 = 3 * SLOT, A2 = 4 * SLOT;
+  static constexpr int STG = B1;                        // epilogue staging: B1 | A2, 8 KiB per wave
+  static constexpr int LDS = 5 * SLOT;                  // 163840
 };
 
-// PERSISTENT: the grid is one workgroup per CU (or fewer tiles); each workgroup walks tiles wg, wg+G, wg+2G, ...
-// A 1-workgroup-per-CU kernel exposes everything between two main loops (epilogue, workgroup launch, the first
-// tile's HBM latency) — measured 46 % of the tile time for K = 768.  Here the NEXT tile's first K-stage is issued by
-// LDS-DMA into ring slot 0 right after the main loop, and the epilogue stages through slot 1, so the DMA flight,
-// the address set-up and the bias load overlap the epilogue's VALU / store work and no launch sits in between.
-template <int EPI, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm256_bf16_kernel(const GemmArgs g) {
-  using C = G256<NW>;
-  constexpr int BN = C::BN;
+#define WAITV(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define WAITL0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
+  using C = G256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / C::WN, wn = wave - wm * C::WN;
+  const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, lh = lane >> 5;
   const int ntiles = g.tiles_m * g.tiles_n;
   const int G = gridDim.x;
   // workgroups b, b+8, .. share an XCD: give each XCD a contiguous run of tile ids inside every round of G tiles
   const int wg = xcd_remap(blockIdx.x, G);
 
-  int a_off[C::TM], a_swz[C::TM], b_off[C::TN], b_swz[C::TN];
+  // Fragment reads.  A lane reads row (wm*128 + i*32 + l31) of the A slot and row (wn*64 + i*32 + l31) of the B slot;
+  // the swizzle (row >> 1) & 7 only sees l31, so one set of four chunk offsets serves every fragment of both
+  // operands and the i*32 rows are immediate offsets of the ds_read.
+  const int lane_a = (wm * 128 + l31) * 128, lane_b = (wn * 64 + l31) * 128;
+  int t16[4];
 #pragma unroll
-  for (int i = 0; i < C::TM; ++i) { const int r = wm * (C::TM * 32) + i * 32 + l31; a_off[i] = r * 128; a_swz[i] = (r >> 1) & 7; }
-#pragma unroll
-  for (int i = 0; i < C::TN; ++i) { const int r = wn * 64 + i * 32 + l31; b_off[i] = C::A_BYTES + r * 128; b_swz[i] = (r >> 1) & 7; }
+  for (int k = 0; k < 4; ++k) t16[k] = ((2 * k + lh) ^ ((l31 >> 1) & 7)) << 4;
 
-  const bf16* a_src[C::GA];
-  const bf16* w_src[C::GB];
+  // per-lane source of the wave's 4 LDS-DMA pieces per operand, as 32-bit element offsets from g.A / g.W (eight
+  // VGPRs instead of sixteen: the kernel lives at the 256-register limit)
+  uint32_t a_src[4], w_src[4];
   int m0 = 0, n0 = 0;
-  float bias_pre[2];
+  float bias_next = 0.f;                                // bias[n0 + wn*64 + lane] of the tile being prefetched
   auto set_tile = [&](int tile) {
     const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;   // N fastest: neighbours share the A panel
-    m0 = tm * C::BM; n0 = tn * BN;
+    m0 = tm * C::BM; n0 = tn * C::BN;
 #pragma unroll
-    for (int i = 0; i < C::GA; ++i) {
-      const int row = (wave + NW * i) * 8 + (lane >> 3);
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave + 8 * i) * 8 + (lane >> 3);
       const int c_src = (lane & 7) ^ ((row >> 1) & 7);
       int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
-      a_src[i] = g.A + (size_t)gr * g.lda + c_src * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < C::GB; ++i) {
-      const int row = (wave + NW * i) * 8 + (lane >> 3);
-      const int c_src = (lane & 7) ^ ((row >> 1) & 7);
-      w_src[i] = g.W + (size_t)(n0 + row) * g.ldw + c_src * 8;
+      a_src[i] = (uint32_t)gr * (uint32_t)g.lda + c_src * 8;
+      w_src[i] = (uint32_t)(n0 + row) * (uint32_t)g.ldw + c_src * 8;
     }
   };
-  auto stage = [&](int slot, int kt) {
-    char* base = smem + slot * C::STAGE;
+  auto piece_a = [&](int off, int kt, int i) { glds16(g.A + (a_src[i] + kt * GEMM_BK), smem + off + (wave + 8 * i) * 1024); };
+  auto piece_b = [&](int off, int kt, int i) { glds16(g.W + (w_src[i] + kt * GEMM_BK), smem + off + (wave + 8 * i) * 1024); };
+  auto stage_a = [&](int off, int kt) {
 #pragma unroll
-    for (int i = 0; i < C::GB; ++i) glds16(w_src[i] + kt * GEMM_BK, base + C::A_BYTES + (wave + NW * i) * 1024);
+    for (int i = 0; i < 4; ++i) piece_a(off, kt, i);
+  };
+  auto stage_b = [&](int off, int kt) {
 #pragma unroll
-    for (int i = 0; i < C::GA; ++i) glds16(a_src[i] + kt * GEMM_BK, base + (wave + NW * i) * 1024);
+    for (int i = 0; i < 4; ++i) piece_b(off, kt, i);
   };
 
   const int nk = g.K / GEMM_BK;
   int tile = wg;
   if (tile < ntiles) {
     set_tile(tile);
-    bias_pre[0] = g.bias[n0 + wn * 64 + l31]; bias_pre[1] = g.bias[n0 + wn * 64 + 32 + l31];
-    stage(0, 0);
+    bias_next = g.bias[n0 + wn * 64 + lane];
+    stage_b(C::B0, 0);
+    stage_a(C::A0, 0);
+    if (nk > 1) stage_a(C::A1, 1);
   }
   STAMP(0);
   RSTAMP(61);
   int tiles_done = 0;
+  bool counted = false;                // previous epilogue took the full-tile path: its last stores may stay in flight
   for (; tile < ntiles; tile += G) {
     ++tiles_done;
     f32x16 acc[C::TM][C::TN];
@@ -117,124 +119,241 @@ __global__ __launch_bounds__(NW * 64) void gemm256_bf16_kernel(const GemmArgs g)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    // stage 0 of this tile was issued before the previous epilogue (or above): drain it (and the epilogue's
-    // stores), then everybody may read slot 0 and DMA may overwrite slot 1 (all staging reads are done).
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    int slot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) stage(slot ^ 1, kt + 1);
-      const char* St = smem + slot * C::STAGE;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int chunk = 2 * s + lh;
-        bf16x8 fa[C::TM], fb[C::TN];
-#pragma unroll
-        for (int i = 0; i < C::TN; ++i) fb[i] = *(const bf16x8*)(St + b_off[i] + ((chunk ^ b_swz[i]) << 4));
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i) fa[i] = *(const bf16x8*)(St + a_off[i] + ((chunk ^ a_swz[i]) << 4));
-#pragma unroll
-        for (int a = 0; a < C::TM; ++a)
-#pragma unroll
-          for (int b = 0; b < C::TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
-      }
-      STAMP(1 + 3 * kt);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      STAMP(2 + 3 * kt);
-      asm volatile("s_barrier" ::: "memory");
-      STAMP(3 + 3 * kt);
-      slot ^= 1;
+    TSTAMP(42);
+    // K-tile 0 needs B(0), A(0).  Younger than those: A(1) (4 DMAs) on the first tile; on later tiles the whole
+    // epilogue — whose last 4 VMEM operations are stores when it ran the full-tile path.
+    if (counted || (tiles_done == 1 && nk > 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else                                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TSTAMP(41);
+    // ---- main loop: two wave groups in ping-pong.  A UNIT is half a K-tile: LOAD = 12 fragment reads
+    // (ds_read_b128), COMPUTE = 16 MFMAs with 4 LDS-DMA pieces issued BETWEEN the MFMAs (s_memtime stamps: a piece
+    // costs ~140 cycles of issue in a burst of four, ~30 behind an MFMA), one s_barrier after each.  Waves 4-7 (the
+    // SIMD partners of waves 0-3) run one barrier behind, so between any two barriers one wave of every SIMD feeds
+    // the matrix pipe while its partner reads LDS:
+    //   phase 4kt  : g0 LOAD(kt,0)                    g1 COMPUTE(kt-1,1) + its B(kt+1) pieces
+    //   phase 4kt+1: g0 COMPUTE(kt,0) + its B(kt+1)   g1 LOAD(kt,0)
+    //   phase 4kt+2: g0 LOAD(kt,1)                    g1 COMPUTE(kt,0) + its A(kt+2) pieces
+    //   phase 4kt+3: g0 COMPUTE(kt,1) + its A(kt+2)   g1 LOAD(kt,1)           every wave: counted vmcnt(4)
+    // K-tile kt is read in phases 4kt..4kt+3 only, so from phase 4kt on B(kt+1) / A(kt+2) may overwrite the slots of
+    // B(kt-1) / A(kt-1).  At the end of phase 4kt+3 the 4 youngest DMAs of every wave are its A(kt+2) pieces: the
+    // counted wait retires its B(kt+1) and A(kt+1) pieces one barrier before their first read (phase 4kt+4).
+    bf16x8 fa[2][C::TM], fb[2][C::TN];
+    int sa = C::A0, sb = C::B0;
+    if (wm) {                                                  // phase 0 of the tile: g1 has no unit to compute yet
+      if (nk > 1) stage_b(C::B1, 1);                           // its B(1) pieces (B1 is free: the tile-start barrier)
+      asm volatile("s_barrier" ::: "memory");                  // the skew
     }
-    STAMP(60);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int sa1 = sa == C::A0 ? C::A1 : (sa == C::A1 ? C::A2 : C::A0);
+      const int sa2 = sa1 == C::A0 ? C::A1 : (sa1 == C::A1 ? C::A2 : C::A0);
+      const int sb1 = sb ^ (C::B0 ^ C::B1);
+      const bool b_on = kt + 1 < nk, a_on = kt + 2 < nk;       // workgroup-uniform
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        // ---------------- LOAD
+        if (half == 0 && kt < 6) TSTAMP(1 + 6 * kt);
+        {
+          const char* As = smem + sa + lane_a;
+          const char* Bs = smem + sb + lane_b;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int o = t16[2 * half + s2];
+#pragma unroll
+            for (int i = 0; i < C::TN; ++i) fb[s2][i] = *(const bf16x8*)(Bs + o + i * 4096);
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) fa[s2][i] = *(const bf16x8*)(As + o + i * 4096);
+          }
+        }
+        if (half == 0 && kt < 6) TSTAMP(2 + 6 * kt);
+        if (half == 1 && wm) {      // g1: end of phase 4kt+3
+          if (a_on) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+          else      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (half == 0 && kt < 6) TSTAMP(3 + 6 * kt);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (half == 0 && kt < 6) TSTAMP(4 + 6 * kt);
+        // ---------------- COMPUTE (+ 4 DMA pieces behind MFMA pairs 1, 3, 5, 7)
+        //   half 0: g0 carries B(kt+1) -> sb1, g1 carries A(kt+2) -> sa2
+        //   half 1: g0 carries A(kt+2) -> sa2, g1 carries B(kt+2) -> sb (K-tile kt's slot: its reads ended a barrier ago)
+        const bool take_a = (half == 0) == (wm != 0);
+        const bool dma_on = (half == 0 && !wm) ? b_on : a_on;
+        const bf16* const dbase = take_a ? g.A : g.W;
+        const int dkoff = ((half == 0 && !wm) ? kt + 1 : kt + 2) * GEMM_BK;
+        const int dlds = take_a ? sa2 : (half == 0 ? sb1 : sb);
+        uint32_t dsrc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dsrc[i] = take_a ? a_src[i] : w_src[i];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int a = 0; a < C::TM; ++a) {
+#pragma unroll
+            for (int b = 0; b < C::TN; ++b)     // operands swapped: D rows <-> n (weight rows), D columns <-> m
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s2][b], fa[s2][a], acc[a][b], 0, 0, 0);
+            const int pair = s2 * 4 + a;        // 8 MFMA pairs per unit
+            if (pair & 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (dma_on) glds16(dbase + (dsrc[pair >> 1] + dkoff), smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        if (half == 0 && kt < 6) TSTAMP(5 + 6 * kt);
+        if (half == 1 && !wm) {     // g0: end of phase 4kt+3
+          if (a_on) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      sa = sa1; sb = sb1;
+    }
+    TSTAMP(60);
 
     // ---------------------------------------------------------------- epilogue
-    const int row0 = m0 + wm * (C::TM * 32), col0 = n0 + wn * 64;
+    // acc[a][b][4q + r]: row m = row0 + a*32 + l31 ; column n = col0 + b*32 + 8q + 4*lh + r
+    const int row0 = m0 + wm * 128, col0 = n0 + wn * 64;
+    const bool full = (m0 + C::BM <= g.M) && (n0 + C::BN <= g.N);    // workgroup-uniform
     const bool wave_cols_ok = col0 < g.N;
-    const float bias0 = bias_pre[0], bias1 = bias_pre[1];
-    // next tile: addresses, bias and the first K-stage go out now, into slot 0 (free since the last barrier)
+    // this tile's bias, one column per lane; the VGPR is consumed here, BEFORE the next DMAs go out, so that the
+    // compiler's wait for the (long finished) bias load cannot land behind them and drain them
+    float bias_lane = bias_next;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(bias_lane));
     const int next = tile + G;
     if (next < ntiles) {
       set_tile(next);
-      bias_pre[0] = g.bias[n0 + wn * 64 + l31]; bias_pre[1] = g.bias[n0 + wn * 64 + 32 + l31];
-      stage(0, 0);
+      bias_next = g.bias[n0 + wn * 64 + lane];
+      stage_b(C::B0, 0);
+      stage_a(C::A0, 0);
+      if (nk > 1) stage_a(C::A1, 1);
     }
-    char* stg = smem + C::STAGE + wave * C::STG;     // wave-private staging inside slot 1
+    TSTAMP(43);
+    // Lane-derived epilogue constants are recomputed per tile behind an opaque copy of the lane id: hoisted out of the
+    // tile loop they would sit in VGPRs across the main loop, which lives at the 256-register limit (a spill reload
+    // is a VMEM operation and would break the counted vmcnt waits below).
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int l31e = le & 31, lhe = le >> 5;
+    float bb[2][4][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bb[b][q][r] = __shfl(bias_lane, b * 32 + 8 * q + 4 * lhe + r);
+    char* const stg = smem + C::STG + wave * 8192;     // wave-private
+    counted = full;
+    // g0 is one barrier short of g1 (the skew): it pays it here, a few hundred cycles into its epilogue, while g1
+    // issues its last 16 MFMAs.
+    if (!wm) asm volatile("s_barrier" ::: "memory");
+
     if (EPI == EPI_BF16 || EPI == EPI_FC1) {   // EPI_FC1 here = bias + erf-GELU, no scoring (evaluation passes)
-      constexpr int PASSES = C::TM * 32 / C::ROWS16, APP = C::ROWS16 / 32;   // 32-row sub-tiles per pass
+      // two passes of 64 rows x 64 columns bf16 (8 KiB): 16-byte chunk c of row r sits at chunk c ^ (r & 7)
+      if (wave_cols_ok) {
+        char* const wr_lane = stg + l31e * 128 + lhe * 8;                       // + a2*4096 + swizzled chunk
+        const char* const rd_lane = stg + (le >> 3) * 128 + (((le & 7) ^ ((le >> 3) & 7)) << 4);   // + it*1024 (8 rows: same r & 7)
+        bf16* const out_lane = g.out + (size_t)(row0 + (le >> 3)) * g.ldo + col0 + (le & 7) * 8;
 #pragma unroll
-      for (int h = 0; h < PASSES; ++h) {
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const float bias = b ? bias1 : bias0;
-          char* const stc = stg + (b * 32 + l31) * 2;
+          for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-          for (int a2 = 0; a2 < APP; ++a2)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-              const int a = h * APP + a2;
-              const int rw = a2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-              uint32_t pk = pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias);
-              if (EPI == EPI_FC1) {
-                f32x2 pre; pre.x = bf16lo_f32(pk); pre.y = bf16hi_f32(pk);
-                const f32x2 gl = gelu_erf_fast2(pre);
-                pk = pack_bf16x2(gl.x, gl.y);
+              for (int q = 0; q < 4; ++q) {
+                const int a = 2 * h + a2;
+                uint32_t pk[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                  pk[p] = pack_bf16x2(acc[a][b][4 * q + 2 * p] + bb[b][q][2 * p], acc[a][b][4 * q + 2 * p + 1] + bb[b][q][2 * p + 1]);
+                  if (EPI == EPI_FC1) {
+                    f32x2 pre; pre.x = bf16lo_f32(pk[p]); pre.y = bf16hi_f32(pk[p]);
+                    const f32x2 gl = gelu_erf_fast2(pre);
+                    pk[p] = pack_bf16x2(gl.x, gl.y);
+                  }
+                }
+                uint2 v; v.x = pk[0]; v.y = pk[1];
+                *(uint2*)(wr_lane + a2 * 4096 + (((b * 4 + q) ^ (l31e & 7)) << 4)) = v;
               }
-              const bf16x2 ov = __builtin_bit_cast(bf16x2, pk);
-              *(bf16*)(stc + rw * 128) = ov[0];
-              *(bf16*)(stc + (rw + 1) * 128) = ov[1];
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (wave_cols_ok) {
+          WAITL0();
+          bf16x8 v[8];
 #pragma unroll
-          for (int it = 0; it < C::ROWS16 / 8; ++it) {
-            const int r = it * 8 + (lane >> 3), c = (lane & 7) * 8;
-            const bf16x8 v = *(const bf16x8*)(stg + r * 128 + c * 2);
-            const int m = row0 + h * C::ROWS16 + r;
-            if (m < g.M) *(bf16x8*)(g.out + (size_t)m * g.ldo + col0 + c) = v;
+          for (int it = 0; it < 8; ++it) v[it] = *(const bf16x8*)(rd_lane + it * 1024);
+          WAITL0();
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            bf16* dst = out_lane + (size_t)(h * 64 + it * 8) * g.ldo;
+            if (full) *(bf16x8*)dst = v[it];
+            else if (row0 + h * 64 + it * 8 + (le >> 3) < g.M) *(bf16x8*)dst = v[it];
           }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-    } else {   // EPI_RESID: fp32 staging of ROWS32 rows x 64 cols per pass, then float4 read-modify-write of x
-      const int c = (lane & 15) * 4;
-      constexpr int PPA = 32 / C::ROWS32;            // passes per 32-row sub-tile (1 or 2)
-      constexpr int IT = C::ROWS32 / 4;              // float4 rows handled per lane per pass (8 or 4)
+      // full path: the last 8 operations of this wave are the second pass's stores; the next main loop starts behind
+      // vmcnt(4), i.e. it waits for everything but the youngest four of them
+    } else {   // EPI_RESID: x += float(bf16(acc + bias)), the fp32 x tile moves through LDS by DMA
+      // block p = (a, b): 32 rows x 32 fp32 columns = 4 KiB, two buffers.  LDS image [32][128 B]; the 16-byte chunk c
+      // of row r sits at chunk c ^ ((r >> 1) & 7) (swizzle applied on the DMA's source address and on the
+      // fragment-shaped accesses; conflict-free ds_read_b128).
+      if (wave_cols_ok) {
+        const int dr = le >> 3;                                      // row inside an 8-row DMA piece
+        float* const xw = g.x + (size_t)row0 * g.ldx + col0;         // wave's 128 x 64 window of x
+        // DMA piece j of a block covers rows 8j .. 8j+7: lane -> (row 8j + dr, LDS chunk le & 7), which holds the
+        // global chunk (le & 7) ^ ((row >> 1) & 7) = c0 ^ 4*(j & 1) with c0 = (le & 7) ^ (dr >> 1)
+        const uint32_t c0 = (uint32_t)((le & 7) ^ (dr >> 1));
+        uint32_t lane_off[2];                                        // element offset inside the block, j even / odd
+        lane_off[0] = (uint32_t)dr * (uint32_t)g.ldx + (c0 << 2);
+        lane_off[1] = (uint32_t)dr * (uint32_t)g.ldx + ((c0 ^ 4u) << 2);
+        const int lim = g.M - 1 - row0;                              // last valid row of the window (edge tiles)
+        auto xptr = [&](int a, int b, int j) -> float* {
+          if (full) return xw + (size_t)((a * 32 + 8 * j) * g.ldx + b * 32) + lane_off[j & 1];
+          int m = a * 32 + 8 * j + dr; m = m < lim ? m : lim;        // clamp: rows past M are read, never stored
+          return xw + (size_t)m * g.ldx + b * 32 + ((c0 ^ ((j & 1) << 2)) << 2);
+        };
+        auto xdma = [&](int p) {
+          const int a = p >> 1, b = p & 1;
 #pragma unroll
-      for (int a = 0; a < C::TM; ++a)
+          for (int j = 0; j < 4; ++j) glds16(xptr(a, b, j), stg + (p & 1) * 4096 + j * 1024);
+        };
+        char* const cell_lane = stg + l31e * 128;
+        const int csw = (l31e >> 1) & 7;
+        xdma(0);
+        xdma(1);
 #pragma unroll
-        for (int hp = 0; hp < PPA; ++hp) {
-          const int rbase = row0 + a * 32 + hp * C::ROWS32;
-          f32x4 xin[IT];
-          float* dst[IT];
-          if (wave_cols_ok) {
+        for (int p = 0; p < 8; ++p) {
+          const int a = p >> 1, b = p & 1;
+          // X(p) has landed: younger than it are S(p-1) and X(p+1)
+          if (!full) WAITV(0);
+          else if (p == 0 || p == 7) WAITV(4);
+          else WAITV(8);
 #pragma unroll
-            for (int it = 0; it < IT; ++it) {
-              const int m = rbase + it * 4 + (lane >> 4);
-              const int mc = m < g.M ? m : g.M - 1;
-              dst[it] = g.x + (size_t)mc * g.ldx + col0 + c;
-              xin[it] = *(const f32x4*)dst[it];
-            }
+          for (int q = 0; q < 4; ++q) {
+            f32x4* cell = (f32x4*)(cell_lane + (p & 1) * 4096 + (((2 * q + lhe) ^ csw) << 4));
+            f32x4 xv = *cell;
+            const uint32_t p0 = pack_bf16x2(acc[a][b][4 * q] + bb[b][q][0], acc[a][b][4 * q + 1] + bb[b][q][1]);
+            const uint32_t p1 = pack_bf16x2(acc[a][b][4 * q + 2] + bb[b][q][2], acc[a][b][4 * q + 3] + bb[b][q][3]);
+            xv.x += bf16lo_f32(p0); xv.y += bf16hi_f32(p0); xv.z += bf16lo_f32(p1); xv.w += bf16hi_f32(p1);
+            *cell = xv;
           }
+          WAITL0();
+          f32x4 v[4];
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+          for (int j = 0; j < 4; ++j) v[j] = *(const f32x4*)(stg + (p & 1) * 4096 + j * 1024 + le * 16);
+          WAITL0();
 #pragma unroll
-            for (int i = hp * (16 / PPA); i < (hp + 1) * (16 / PPA); ++i) {
-              const int rw = (i & 3) + 8 * (i >> 2) + 4 * lh - hp * C::ROWS32;     // row inside this pass
-              *(float*)(stg + rw * 256 + (b * 32 + l31) * 4) = bf16_round(acc[a][b][i] + (b ? bias1 : bias0));
-            }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (wave_cols_ok) {
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-              const int r = it * 4 + (lane >> 4);
-              const f32x4 v = *(const f32x4*)(stg + r * 256 + c * 4);
-              if (rbase + r < g.M) *(f32x4*)dst[it] = xin[it] + v;
-            }
+          for (int j = 0; j < 4; ++j) {
+            float* dst = xptr(a, b, j);
+            if (full) *(f32x4*)dst = v[j];
+            else if (row0 + a * 32 + 8 * j + dr < g.M) *(f32x4*)dst = v[j];
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites the staging
+          if (p + 2 < 8) xdma(p + 2);          // buffer p&1 is free: its read-out has landed in registers
         }
+      }
     }
+    TSTAMP(40);
   }
   STAMP(59);
   RSTAMP(62);

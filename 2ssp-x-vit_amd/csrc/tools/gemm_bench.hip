@@ -1,5 +1,6 @@
 // Standalone micro-benchmark of gemm_bf16_kernel<EPI> on random bf16 data (HIP events, median of rounds).
-//   gemm_bench.bin M N K epi [iters] [tokens]       epi: 0 bf16, 1 resid, 2 fc1(+score), 3 patch, 4 f32
+//   gemm_bench.bin M N K epi [iters] [tokens]       epi: 0 bf16, 1 resid, 2 fc1(+score), 3 patch, 4 f32 (128x128 kernel);
+//   10/11/12 bf16/resid/fc1 on the persistent 256x256 kernel, 20/21/22 the same on its round-1 version (A/B)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -7,6 +8,7 @@
 #include <cstring>
 #include <vector>
 #include "../gemm256.hip.h"
+#include "gemm256_v1.hip.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -19,11 +21,17 @@ template <int EPI, int SCORE = 0> static void launch(const GemmArgs& g, hipStrea
 }
 
 static int nCU = 256;
-template <int EPI, int NW> static void launch256(GemmArgs g, hipStream_t s) {
+template <int EPI> static void launch256(GemmArgs g, hipStream_t s) {
   static bool done = false;
-  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<NW>::LDS)); done = true; }
+  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS)); done = true; }
   g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
-  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, NW>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(NW * 64), G256<NW>::LDS, s, g);
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(512), G256::LDS, s, g);
+}
+template <int EPI, int NW> static void launch256v1(GemmArgs g, hipStream_t s) {   // round-1 kernel, A/B reference
+  static bool done = false;
+  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256v1_bf16_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, G256v1<NW>::LDS)); done = true; }
+  g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
+  hipLaunchKernelGGL((gemm256v1_bf16_kernel<EPI, NW>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(NW * 64), G256v1<NW>::LDS, s, g);
 }
 
 int main(int argc, char** argv) {
@@ -53,8 +61,10 @@ int main(int argc, char** argv) {
   auto run = [&]() {
     switch (epi) { case 0: launch<EPI_BF16>(g, s); break; case 1: launch<EPI_RESID>(g, s); break; case 2: launch<EPI_FC1, 1>(g, s); break; case 5: launch<EPI_FC1, 2>(g, s); break; case 6: launch<EPI_FC1, 0>(g, s); break;
                    case 3: launch<EPI_PATCH>(g, s); break; case 4: launch<EPI_F32>(g, s); break;
-                   case 10: launch256<EPI_BF16, 8>(g, s); break; case 11: launch256<EPI_RESID, 8>(g, s); break;
-                   case 12: launch256<EPI_FC1, 8>(g, s); break; case 30: launch256<EPI_BF16, 16>(g, s); break; case 31: launch256<EPI_RESID, 16>(g, s); break;
+                   case 10: launch256<EPI_BF16>(g, s); break; case 11: launch256<EPI_RESID>(g, s); break;
+                   case 12: launch256<EPI_FC1>(g, s); break;
+                   case 20: launch256v1<EPI_BF16, 8>(g, s); break; case 21: launch256v1<EPI_RESID, 8>(g, s); break;
+                   case 22: launch256v1<EPI_FC1, 8>(g, s); break;
                    default: break; }
   };
   if (epi >= 10) {   // verify the large-tile kernel against the (oracle-validated) 128x128 kernel, bit for bit
@@ -106,10 +116,24 @@ int main(int argc, char** argv) {
            mfma / cnt, wait / cnt, bar / cnt, tot / nb, (double)(tmax - tmin));
     if (epi >= 10) {   // persistent kernel: per-workgroup totals
       int G = std::min(((M + 255) / 256) * ((N + 255) / 256), nCU);
-      double cyc = 0, rt = 0, tl = 0, loop1 = 0;
-      for (int b = 0; b < G; ++b) { const unsigned long long* t = &h[(size_t)b * 64]; cyc += (double)(t[59] - t[0]); rt += (double)(t[62] - t[61]); tl += (double)t[63]; loop1 += (double)(t[60] - t[0]); }
-      printf("persistent: %d workgroups, avg tiles/wg %.2f, avg lifetime %.0f cycles = %.1f us (s_memrealtime, 100 MHz) -> clock %.2f GHz ; cycles per tile %.0f ; last tile main loop %.0f\n",
-             G, tl / G, cyc / G, rt / G / 100.0, (cyc / G) / (rt / G / 100.0) / 1e3, cyc / tl, loop1 / G);
+      double cyc = 0, rt = 0, tl = 0;
+      for (int b = 0; b < G; ++b) { const unsigned long long* t = &h[(size_t)b * 64]; cyc += (double)(t[59] - t[0]); rt += (double)(t[62] - t[61]); tl += (double)t[63]; }
+      printf("persistent: %d workgroups, avg tiles/wg %.2f, avg lifetime %.0f cycles = %.1f us (s_memrealtime, 100 MHz) -> clock %.2f GHz ; cycles per tile %.0f\n",
+             G, tl / G, cyc / G, rt / G / 100.0, (cyc / G) / (rt / G / 100.0) / 1e3, cyc / tl);
+      if (epi < 20) {  // third tile of every workgroup that ran >= 3: tile-start wait, main loop (compute / wait / barrier per K-tile), prefetch issue, epilogue
+        double w0 = 0, ml = 0, pf = 0, ep = 0, d[4] = {0, 0, 0, 0}, per = 0; long n = 0, nkt = 0;
+        for (int b = 0; b < G; ++b) {
+          const unsigned long long* t = &h[(size_t)b * 64];
+          if (t[63] < 3 || !t[40] || !t[41]) continue;
+          w0 += (double)(t[41] - t[42]); ml += (double)(t[60] - t[41]); pf += (double)(t[43] - t[60]); ep += (double)(t[40] - t[43]); ++n;
+          for (int k = 1; k < nk && k < 6; ++k) {
+            for (int j = 0; j < 4; ++j) d[j] += (double)(t[2 + 6 * k + j] - t[1 + 6 * k + j]);
+            per += (double)(t[1 + 6 * k] - t[1 + 6 * (k - 1)]); ++nkt;
+          }
+        }
+        if (n) printf("third tile (wave 0, avg of %ld workgroups, cycles): start-wait+barrier %.0f | main loop %.0f (K-tile period %.0f; first unit: 12 ds_read issue %.0f, lgkmcnt wait %.0f, barrier %.0f, 16 MFMA + 4 DMA issue %.0f) | next-tile set-up + DMA issue %.0f | epilogue %.0f\n",
+                      n, w0 / n, ml / n, per / nkt, d[0] / nkt, d[1] / nkt, d[2] / nkt, d[3] / nkt, pf / n, ep / n);
+      }
     }
     // distribution of block start times (first 16 and a few later)
     for (int b : {0, 1, 255, 256, 511, 512, 513, 1000, 2000}) if (b < nb) printf("  block %d start %+lld loop %lld\n", b, (long long)(h[(size_t)b * 64] - tmin), (long long)(h[(size_t)b * 64 + 60] - h[(size_t)b * 64]));
