@@ -26,8 +26,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DT = (DH + 31) / 32;     // 32-row tiles of the O^T output (d_h padded up)
   constexpr int KS = DH / 16;            // k-steps of the QK^T product
-  constexpr int KSB = DH * 2 + 16;       // K row stride (bytes): conflict-free ds_read_b128
-  constexpr int VSB = 192;               // V row stride (bytes): 48 dwords -> 4 rows x 16 dwords tile 64 banks
+  // d_h = 64 (Ti/S/B/L): rows are exactly 128 B, so K and V are staged by LDS-DMA (lane-linear image, 8 rows per
+  // 1-KiB piece, every piece of the head in flight at once) and bank conflicts are removed by XOR swizzles applied on
+  // the DMA's source address and again on the reads:  K chunk ^= (row >> 1) & 7  (ds_read_b128, lane <-> row),
+  // V 64-byte half ^= (row >> 1) & 1  (ds_read_b64_tr_b16: 4 rows x 64 B per 32-lane group).
+  // Other head widths (80: H/14) keep padded rows filled through registers.
+  constexpr bool DMA = (DH == 64);
+  constexpr int KSB = DMA ? 128 : DH * 2 + 16;       // K row stride (bytes): conflict-free ds_read_b128
+  constexpr int VSB = DMA ? 128 : 192;               // V row stride (bytes): 48 dwords -> 4 rows x 16 dwords tile 64 banks
   constexpr int NKEY = NT * 32;
   constexpr int CH = DH / 8;
   static_assert(DT * 32 * 2 <= VSB, "V row does not fit its LDS stride");
@@ -40,7 +46,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const size_t img_row = (size_t)row_of(rm, img);
   const bf16* base = qkv + img_row * ld + head * DH;
 
-  // ---- stage K, V (zero rows past `tokens`, zero V columns past d_h: 0 * garbage would be NaN-unsafe)
+  // ---- stage K, V
+  if constexpr (DMA) {
+    // rows past `tokens` copy the last valid row: finite values, masked out of the softmax (p = 0) below
+    for (int piece = wave; piece < NKEY / 8; piece += 4) {
+      const int row = piece * 8 + (lane >> 3), c = lane & 7;
+      const int rc = row < tokens ? row : tokens - 1;
+      const bf16* rowp = base + (size_t)rc * ld;
+      glds16(rowp + dim + ((c ^ ((row >> 1) & 7)) << 3), Ks + piece * 1024);
+      glds16(rowp + 2 * dim + ((c ^ (((row >> 1) & 1) << 2)) << 3), Vs + piece * 1024);
+    }
+  } else
+  // (zero rows past `tokens`, zero V columns past d_h: 0 * garbage would be NaN-unsafe)
   for (int idx = tid; idx < NKEY * CH; idx += 256) {
     const int key = idx / CH, c = idx - key * CH;
     bf16x8 kv, vv;
@@ -64,11 +81,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       *(bf16x8*)(Vs + key * VSB + (CH + c) * 16) = z;
     }
   }
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // per-lane constants of the transposed V read: 16-lane group -> 16 d_h columns, lane 4q+p -> row q, cols 4p..
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
   const int v_lane_off = (4 * lh + tr_q) * VSB + (16 * tr_g + 4 * tr_p) * 2;
+  const int v_sw = DMA ? ((tr_q >> 1) & 1) : 0;          // swizzle bit of this lane's V rows (row bit 1 == tr_q bit 1)
+  const int k_sw = DMA ? ((l31 >> 1) & 7) : 0;
 
   const bf16* qbase = (CLS_ONLY ? qsrc + (size_t)img * q_img_stride : qsrc + img_row * ld) + head * DH;
   for (int qt = wave; qt < (CLS_ONLY ? 1 : NT); qt += 4) {   // wave-uniform trip count: EXEC stays full
@@ -84,10 +104,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) sacc[kt][i] = 0.f;
-      const char* kp = Ks + (kt * 32 + l31) * KSB + 16 * lh;
+      const char* kp = Ks + (kt * 32 + l31) * KSB + (DMA ? 0 : 16 * lh);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const bf16x8 kf = *(const bf16x8*)(kp + 32 * s);
+        const bf16x8 kf = *(const bf16x8*)(kp + (DMA ? (((2 * s + lh) ^ k_sw) << 4) : 32 * s));
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
       }
     }
@@ -137,9 +157,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (__attribute__((address_space(3))) bf16x4*)(vp + dt * 64));
+              (__attribute__((address_space(3))) bf16x4*)(vp + (dt ^ v_sw) * 64));
           const bf16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (__attribute__((address_space(3))) bf16x4*)(vp + dt * 64 + 8 * VSB));
+              (__attribute__((address_space(3))) bf16x4*)(vp + (dt ^ v_sw) * 64 + 8 * VSB));
           bf16x8 vf;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { vf[j] = v1[j]; vf[4 + j] = v2[j]; }
@@ -147,7 +167,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         }
       }
     }
-    // ---- store: lane <-> query row, 4 consecutive d_h per 8-byte store
+    // ---- store
+    if constexpr (DMA && !CLS_ONLY) {
+      // through a wave-private [32 queries][128 B] LDS tile (chunk ^= row & 7), so that every global store is a whole
+      // 128-byte row segment of 8 lanes x 16 B instead of 8 bytes per lane at a row stride
+      char* ost = smem + 2 * NKEY * 128 + wave * 4096;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          bf16x4 o4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o4[j] = (bf16)(oacc[dt][4 * g4 + j] * inv);
+          *(bf16x4*)(ost + l31 * 128 + (((dt * 4 + g4) ^ (l31 & 7)) << 4) + lh * 8) = o4;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bf16x8 ov[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3);
+        ov[it] = *(const bf16x8*)(ost + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int qq = qt * 32 + it * 8 + (lane >> 3);
+        if (qq < tokens) *(bf16x8*)(out + img_row * ldo + (size_t)qq * ldo + head * DH + (lane & 7) * 8) = ov[it];
+      }
+    } else
+    // lane <-> query row, 4 consecutive d_h per 8-byte store
     if (CLS_ONLY ? (q == 0) : (q < tokens)) {
       bf16* op = (CLS_ONLY ? out + (size_t)img * o_img_stride : out + img_row * ldo) + (size_t)q * ldo + head * DH;
 #pragma unroll
