@@ -21,6 +21,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// the same with the NT (non-temporal) cache policy: a streamed operand takes the L2's evict-first position, so that it
+// does not push the panels that every tile re-reads (weights) out of the 4 MiB L2
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+
 // exact (erf) GELU in fp32, the nn.GELU() default the reference models use
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

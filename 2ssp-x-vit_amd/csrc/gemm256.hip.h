@@ -34,6 +34,21 @@
 #define RSTAMP(slot) do {} while (0)
 #endif
 
+// Cache policy of the streamed traffic (activation panel, x tile, outputs).  GEMM_NT=1 marks it non-temporal so that
+// it cannot evict the weight panels from the XCD's 4 MiB L2.  Measured (gemm_bench + rocprofv3 PMC, 63040-row shapes):
+// QKV's HBM-side fetch halves (182 -> 99 MB per launch, L2 hit rate 72 -> 79 %) and yet every shape runs 5-9 % SLOWER,
+// so the default policy stays; the switch is kept for A/B runs only.
+#ifndef GEMM_NT
+#define GEMM_NT 0
+#endif
+#if GEMM_NT
+#define GLDS_A glds16_nt
+#define ST_OUT(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define GLDS_A glds16
+#define ST_OUT(p, v) (*(p) = (v))
+#endif
+
 struct G256 {
   static constexpr int BM = 256, BN = 256, NW = 8;
   static constexpr int TM = 4, TN = 2;                  // 32x32 MFMA tiles per wave along M / N
@@ -85,7 +100,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       w_src[i] = (uint32_t)(n0 + row) * (uint32_t)g.ldw + c_src * 8;
     }
   };
-  auto piece_a = [&](int off, int kt, int i) { glds16(g.A + (a_src[i] + kt * GEMM_BK), smem + off + (wave + 8 * i) * 1024); };
+  auto piece_a = [&](int off, int kt, int i) { GLDS_A(g.A + (a_src[i] + kt * GEMM_BK), smem + off + (wave + 8 * i) * 1024); };
   auto piece_b = [&](int off, int kt, int i) { glds16(g.W + (w_src[i] + kt * GEMM_BK), smem + off + (wave + 8 * i) * 1024); };
   auto stage_a = [&](int off, int kt) {
 #pragma unroll
@@ -197,7 +212,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             const int pair = s2 * 4 + a;        // 8 MFMA pairs per unit
             if (pair & 1) {
               __builtin_amdgcn_sched_barrier(0);
-              if (dma_on) glds16(dbase + (dsrc[pair >> 1] + dkoff), smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
+              if (dma_on) {
+                if (take_a) GLDS_A(dbase + (dsrc[pair >> 1] + dkoff), smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
+                else        glds16(dbase + (dsrc[pair >> 1] + dkoff), smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
+              }
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -287,8 +305,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
           for (int it = 0; it < 8; ++it) {
             bf16* dst = out_lane + (size_t)(h * 64 + it * 8) * g.ldo;
-            if (full) *(bf16x8*)dst = v[it];
-            else if (row0 + h * 64 + it * 8 + (le >> 3) < g.M) *(bf16x8*)dst = v[it];
+            if (full) ST_OUT((bf16x8*)dst, v[it]);
+            else if (row0 + h * 64 + it * 8 + (le >> 3) < g.M) ST_OUT((bf16x8*)dst, v[it]);
           }
         }
       }
@@ -316,7 +334,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         auto xdma = [&](int p) {
           const int a = p >> 1, b = p & 1;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) glds16(xptr(a, b, j), stg + (p & 1) * 4096 + j * 1024);
+          for (int j = 0; j < 4; ++j) GLDS_A(xptr(a, b, j), stg + (p & 1) * 4096 + j * 1024);
         };
         char* const cell_lane = stg + l31e * 128;
         const int csw = (l31e >> 1) & 7;
@@ -325,7 +343,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
           const int a = p >> 1, b = p & 1;
-          // X(p) has landed: younger than it are S(p-1) and X(p+1)
+          // X(p) has landed: younger than it are S(p-1) and X(p+1).  (Touching the lines of blocks 2..7 ahead of
+          // their DMAs — one global_load_dword per 128-byte line at the start of the epilogue — was tried and made
+          // proj / fc2 3-7 % slower: the path is short of memory-level parallelism, not of L2 locality.)
           if (!full) WAITV(0);
           else if (p == 0 || p == 7) WAITV(4);
           else WAITV(8);
@@ -346,8 +366,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float* dst = xptr(a, b, j);
-            if (full) *(f32x4*)dst = v[j];
-            else if (row0 + a * 32 + 8 * j + dr < g.M) *(f32x4*)dst = v[j];
+            if (full) ST_OUT((f32x4*)dst, v[j]);
+            else if (row0 + a * 32 + 8 * j + dr < g.M) ST_OUT((f32x4*)dst, v[j]);
           }
           if (p + 2 < 8) xdma(p + 2);          // buffer p&1 is free: its read-out has landed in registers
         }

@@ -39,9 +39,11 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 def pmc_traffic():
     """HBM bytes per fc1 launch (launch-weighted over the same launch mix), from the committed rocprofv3 PMC passes
-    (scripts/pmc_traffic.sh -> profiles/r01_pmc_traffic.json; counters cannot be read from inside the process)."""
+    (scripts/pmc_traffic.sh -> profiles/r<round>_<tag>_pmc_traffic.json, newest file; counters cannot be read from inside the process)."""
+    import glob
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        with open(newest) as f:
             return int(json.load(f)["fc1_family"]["avg_hbm_bytes_per_launch"])
     except Exception:
         return None
@@ -227,7 +229,7 @@ def main():
                                 "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
                                 "flops_per_launch_avg": prof.flops / prof.launches,
-                                "shapes": f"[{args.batch * tokens} | {n_eval * tokens} | {n_eval}] x {d_int} x {dim} (stage-1 batch | search chunk | CLS tail)"}
+                                "shapes": f"[{eng.rows(min(args.calib, args.calib_chunk or args.batch), args.batch)} | {(args.eval_chunk or n_eval) * tokens} | {n_eval}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk | CLS tail)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, weights)
         print(json.dumps(line), flush=True)

@@ -26,7 +26,7 @@ for k in fetch:
     rows.append({"kernel": k[0][-48:], "grid": k[1], "launches": len(fetch[k]), "fetch_bytes_per_launch": round(f),
                  "write_bytes_per_launch": round(w), "hbm_bytes_per_launch": round(f + w)})
 rows.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
-fc1 = [r for r in rows if "gemm_bf16_kernel<2," in r["kernel"] or "gemm256_bf16_kernel<2," in r["kernel"]]   # EPI_FC1, both tile shapes
+fc1 = [r for r in rows if "gemm_bf16_kernel<2," in r["kernel"] or "gemm256_bf16_kernel<2" in r["kernel"]]   # EPI_FC1, both tile shapes
 n = sum(r["launches"] for r in fc1)
 avg = sum(r["launches"] * r["hbm_bytes_per_launch"] for r in fc1) / max(1, n)
 print(json.dumps({"unit": "bytes per launch; FETCH_SIZE doubled (gfx950), KiB->B; Infinity-Cache hits count as traffic",
