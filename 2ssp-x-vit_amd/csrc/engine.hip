@@ -147,17 +147,17 @@ struct ProfScope {
 // Large-M projections go to the 256 x 256 tile kernel (bit-identical results, fewer LDS-DMA issues per MFMA);
 // everything else (small M, fused fc1 epilogue, patch embed, head) stays on the 128 x 128 kernel.
 static const int kBigTileMinRows = 4096;
-template <int EPI>
+template <int EPI, int SCORE = 0>
 static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS));
     attr_done = true;
   }
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
-  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI>), dim3(std::min(g.tiles_m * g.tiles_n, e->n_cu)), dim3(512), G256::LDS, e->stream, g);
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE>), dim3(std::min(g.tiles_m * g.tiles_n, e->n_cu)), dim3(512), G256::LDS, e->stream, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -165,9 +165,9 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
 template <int EPI, int SCORE = 0>
 static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
   if (g.K % GEMM_BK) return fail(SSP2_EINVAL, "GEMM K=%d not a multiple of %d", g.K, GEMM_BK);
-  if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID || (EPI == EPI_FC1 && SCORE == 0)) {
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID || EPI == EPI_FC1) {
     static const bool fc1_big = !getenv("SSP2_FC1_SMALL_TILES");
-    if (g.M >= kBigTileMinRows && !(EPI == EPI_FC1 && (g.out2 || !fc1_big)) && !getenv("SSP2_NO_BIG_TILES")) return launch_gemm256<EPI>(e, g, klass);
+    if (g.M >= kBigTileMinRows && !(EPI == EPI_FC1 && (g.out2 || !fc1_big)) && !getenv("SSP2_NO_BIG_TILES")) return launch_gemm256<EPI, SCORE>(e, g, klass);
   }
   g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
   if (g.tiles_m <= 0 || g.tiles_n <= 0) return fail(SSP2_EINVAL, "empty GEMM");

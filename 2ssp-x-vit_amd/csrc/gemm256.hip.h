@@ -61,9 +61,15 @@ struct G256 {
 #define WAITV(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAITL0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int EPI>
+// SCORE (EPI_FC1 only): 0 none (evaluation passes), 1 pre-GELU, 2 post-GELU stage-1 score.  The scoring variant
+// keeps the PLAIN operand order (lane <-> column, registers <-> rows): the per-(sample, neuron) sums of squares are then
+// in-lane accumulations, and every partial sum is formed in exactly the order of gemm_bf16_kernel<EPI_FC1, SCORE>
+// (a wave's 128 rows = that kernel's 128-row tile, passes h = 0, 1 = its row-waves), so the slab — and the stage-1
+// scores — are bit-identical whichever kernel a launch is routed to.
+template <int EPI, int SCORE = 0>
 __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   using C = G256;
+  constexpr bool SWAP = !(EPI == EPI_FC1 && SCORE != 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -208,7 +214,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
           for (int a = 0; a < C::TM; ++a) {
 #pragma unroll
             for (int b = 0; b < C::TN; ++b)     // operands swapped: D rows <-> n (weight rows), D columns <-> m
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s2][b], fa[s2][a], acc[a][b], 0, 0, 0);
+              acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s2][b], fa[s2][a], acc[a][b], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][a], fb[s2][b], acc[a][b], 0, 0, 0);
             const int pair = s2 * 4 + a;        // 8 MFMA pairs per unit
             if (pair & 1) {
               __builtin_amdgcn_sched_barrier(0);
@@ -264,11 +271,88 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bb[b][q][r] = __shfl(bias_lane, b * 32 + 8 * q + 4 * lhe + r);
     char* const stg = smem + C::STG + wave * 8192;     // wave-private
-    counted = full;
+    counted = full && SWAP;
     // g0 is one barrier short of g1 (the skew): it pays it here, a few hundred cycles into its epilogue, while g1
     // issues its last 16 MFMAs.
     if (!wm) asm volatile("s_barrier" ::: "memory");
 
+    if constexpr (!SWAP) {
+      // ---- fc1 + GELU + stage-1 score, plain layout: acc[a][b][i]: row = row0 + a*32 + (i&3) + 8*(i>>2) + 4*lh,
+      // column = col0 + b*32 + l31.  Same arithmetic, in the same order, as gemm_bf16_kernel<EPI_FC1, SCORE>.
+      const float bias2[2] = {__shfl(bias_lane, l31e), __shfl(bias_lane, 32 + l31e)};
+      const int m128 = row0;                           // this wave's 128-row tile (= one tile of the 128x128 kernel); m0 already names the NEXT tile
+      int bnd = 1 << 30, row_lim = g.M - m128;         // rows of the tile at or past row_lim never count
+      {
+        int ml0 = m128;
+        if (g.group > 0) {
+          const int sbk = m128 / g.mpad;
+          ml0 = m128 - sbk * g.mpad;
+          const int imgs = min(g.group, g.n_img - sbk * g.group);
+          row_lim = imgs * g.tokens - ml0;
+        }
+        bnd = (ml0 / g.tokens + 1) * g.tokens - ml0;   // first row (inside the tile) that belongs to the NEXT sample
+      }
+      float ssq[2][2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};     // [pass h][segment][b]
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float bias = bias2[b];
+          char* const stc = stg + (b * 32 + l31e) * 2;
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2) {
+            const int a = 2 * h + a2;
+            const int rb = h * 64 + a2 * 32;           // does this 32-row sub-tile lie wholly inside one sample and inside M?
+            const bool plain = (rb + 32 <= bnd || rb >= bnd) && (rb + 32 <= row_lim);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+              const int rw = a2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * lhe;     // row inside the 64-row pass (i even: rw, rw+1)
+              const uint32_t pk = pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias);
+              f32x2 pre; pre.x = bf16lo_f32(pk); pre.y = bf16hi_f32(pk);
+              const f32x2 gl = gelu_erf_fast2(pre);
+              const uint32_t o = pack_bf16x2(gl.x, gl.y);
+              f32x2 sv = pre;
+              if (SCORE == 2) { sv.x = bf16lo_f32(o); sv.y = bf16hi_f32(o); }
+              if (plain) {
+                s0 = fmaf(sv.x, sv.x, s0); s0 = fmaf(sv.y, sv.y, s0);
+              } else {                                   // sub-tile straddles two samples or the end of the slab / of M
+                const int r0 = h * 64 + rw;
+                const float q0 = (r0 < row_lim) ? sv.x * sv.x : 0.f, q1 = (r0 + 1 < row_lim) ? sv.y * sv.y : 0.f;
+                if (r0 < bnd) s0 += q0; else s1 += q0;
+                if (r0 + 1 < bnd) s0 += q1; else s1 += q1;
+              }
+              const bf16x2 ov = __builtin_bit_cast(bf16x2, o);
+              *(bf16*)(stc + rw * 128) = ov[0];
+              *(bf16*)(stc + (rw + 1) * 128) = ov[1];
+            }
+            if (plain && rb >= bnd) { ssq[h][1][b] += s0; } else { ssq[h][0][b] += s0; ssq[h][1][b] += s1; }
+          }
+        }
+        WAITL0();
+        if (wave_cols_ok) {
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int r = it * 8 + (le >> 3), c = (le & 7) * 8;
+            const bf16x8 v = *(const bf16x8*)(stg + r * 128 + c * 2);
+            const int m = row0 + h * 64 + r;
+            if (m < g.M) *(bf16x8*)(g.out + (size_t)m * g.ldo + col0 + c) = v;
+          }
+        }
+        WAITL0();
+      }
+      // lane l31 of both halves holds the same column: fold the halves of each pass, then the two passes
+#pragma unroll
+      for (int sgm = 0; sgm < 2; ++sgm)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float t0 = ssq[0][sgm][b], t1 = ssq[1][sgm][b];
+          t0 += __shfl_xor(t0, 32);
+          t1 += __shfl_xor(t1, 32);
+          const int col = col0 + b * 32 + l31e;
+          if (lhe == 0 && col < g.slab_ld) g.slab[((size_t)(m128 >> 7) * 2 + sgm) * g.slab_ld + col] = t0 + t1;
+        }
+    } else
     if (EPI == EPI_BF16 || EPI == EPI_FC1) {   // EPI_FC1 here = bias + erf-GELU, no scoring (evaluation passes)
       // two passes of 64 rows x 64 columns bf16 (8 KiB): 16-byte chunk c of row r sits at chunk c ^ (r & 7)
       if (wave_cols_ok) {

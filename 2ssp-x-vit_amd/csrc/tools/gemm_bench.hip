@@ -21,11 +21,11 @@ template <int EPI, int SCORE = 0> static void launch(const GemmArgs& g, hipStrea
 }
 
 static int nCU = 256;
-template <int EPI> static void launch256(GemmArgs g, hipStream_t s) {
+template <int EPI, int SCORE = 0> static void launch256(GemmArgs g, hipStream_t s) {
   static bool done = false;
-  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS)); done = true; }
+  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS)); done = true; }
   g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
-  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(512), G256::LDS, s, g);
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(512), G256::LDS, s, g);
 }
 template <int EPI, int NW> static void launch256v1(GemmArgs g, hipStream_t s) {   // round-1 kernel, A/B reference
   static bool done = false;
@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
   GemmArgs g{};
   g.A = A; g.lda = K; g.W = W; g.ldw = K; g.bias = bias; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + 127) / 128; g.tiles_n = Npad / 128; g.out = out; g.ldo = Npad; g.x = x; g.ldx = Npad;
-  g.score_site = epi == 2 ? 1 : (epi == 5 ? 2 : 0); g.tokens = tokens; g.slab = slab; g.slab_ld = Npad; g.pos = pos; g.patches = 196; g.group_m = argc > 7 ? atoi(argv[7]) : 0;
+  g.score_site = (epi == 2 || epi == 13) ? 1 : ((epi == 5 || epi == 14) ? 2 : 0); g.tokens = tokens; g.slab = slab; g.slab_ld = Npad; g.pos = pos; g.patches = 196; g.group_m = argc > 7 ? atoi(argv[7]) : 0;
 #ifdef GEMM_STAMPS
   unsigned long long* stamps; CK(hipMalloc(&stamps, (size_t)g.tiles_m * g.tiles_n * 64 * 8)); CK(hipMemset(stamps, 0, (size_t)g.tiles_m * g.tiles_n * 64 * 8));
   g.stamps = stamps;
@@ -62,18 +62,22 @@ int main(int argc, char** argv) {
     switch (epi) { case 0: launch<EPI_BF16>(g, s); break; case 1: launch<EPI_RESID>(g, s); break; case 2: launch<EPI_FC1, 1>(g, s); break; case 5: launch<EPI_FC1, 2>(g, s); break; case 6: launch<EPI_FC1, 0>(g, s); break;
                    case 3: launch<EPI_PATCH>(g, s); break; case 4: launch<EPI_F32>(g, s); break;
                    case 10: launch256<EPI_BF16>(g, s); break; case 11: launch256<EPI_RESID>(g, s); break;
-                   case 12: launch256<EPI_FC1>(g, s); break;
+                   case 12: launch256<EPI_FC1>(g, s); break; case 13: launch256<EPI_FC1, 1>(g, s); break; case 14: launch256<EPI_FC1, 2>(g, s); break;
                    case 20: launch256v1<EPI_BF16, 8>(g, s); break; case 21: launch256v1<EPI_RESID, 8>(g, s); break;
                    case 22: launch256v1<EPI_FC1, 8>(g, s); break;
                    default: break; }
   };
   if (epi >= 10) {   // verify the large-tile kernel against the (oracle-validated) 128x128 kernel, bit for bit
-    const bool resid = (epi % 10) == 1, fc1 = (epi % 10) == 2;
+    const bool resid = (epi % 10) == 1, fc1 = (epi % 10) == 2, sc1 = epi == 13, sc2 = epi == 14;
+    const size_t se = (size_t)((M + 127) / 128) * 2 * Npad;
+    std::vector<float> slab_ref(se);
     size_t xe = (size_t)(M + M / 196 + 2) * Npad, oe = (size_t)M * Npad;
     CK(hipMemset(x, 0, xe * 4)); CK(hipMemset(out, 0, oe * 2));
     GemmArgs r = g; r.tiles_m = (M + 127) / 128; r.tiles_n = Npad / 128;
-    if (resid) launch<EPI_RESID>(r, s); else if (fc1) launch<EPI_FC1, 0>(r, s); else launch<EPI_BF16>(r, s);
+    if (sc1 || sc2) CK(hipMemset(slab, 0, se * 4));
+    if (resid) launch<EPI_RESID>(r, s); else if (fc1) launch<EPI_FC1, 0>(r, s); else if (sc1) launch<EPI_FC1, 1>(r, s); else if (sc2) launch<EPI_FC1, 2>(r, s); else launch<EPI_BF16>(r, s);
     CK(hipStreamSynchronize(s));
+    if (sc1 || sc2) { CK(hipMemcpy(slab_ref.data(), slab, se * 4, hipMemcpyDeviceToHost)); CK(hipMemset(slab, 0, se * 4)); }
     std::vector<float> xr(resid ? xe : 0); std::vector<uint16_t> orf(resid ? 0 : oe);
     if (resid) CK(hipMemcpy(xr.data(), x, xe * 4, hipMemcpyDeviceToHost)); else CK(hipMemcpy(orf.data(), out, oe * 2, hipMemcpyDeviceToHost));
     CK(hipMemset(x, 0, xe * 4)); CK(hipMemset(out, 0, oe * 2));
@@ -83,6 +87,13 @@ int main(int argc, char** argv) {
                  for (size_t i = 0; i < (size_t)M * Npad; ++i) { size_t rr = i / Npad, cc = i % Npad; if ((int)cc < N && memcmp(&xn[rr * Npad + cc], &xr[rr * Npad + cc], 4)) ++bad; } }
     else { std::vector<uint16_t> on(oe); CK(hipMemcpy(on.data(), out, oe * 2, hipMemcpyDeviceToHost));
            for (size_t i = 0; i < oe; ++i) { if ((int)(i % Npad) < N && on[i] != orf[i]) ++bad; } }
+    if (sc1 || sc2) {
+      std::vector<float> sn(se); CK(hipMemcpy(sn.data(), slab, se * 4, hipMemcpyDeviceToHost));
+      size_t sbad = 0; double ssum = 0;
+      for (size_t i = 0; i < se; ++i) { if ((int)(i % Npad) < N) { if (memcmp(&sn[i], &slab_ref[i], 4)) { if (sbad < 12) printf("  slab[tile %zu seg %zu col %zu] = %.9g vs ref %.9g\n", i / Npad / 2, (i / Npad) % 2, i % Npad, sn[i], slab_ref[i]); ++sbad; } ssum += sn[i]; } }
+      printf("score slab vs 128x128 kernel: %zu mismatching of %zu (sum %.6g)%s\n", sbad, se, ssum, sbad ? "  <-- FAIL" : " (bit-identical)");
+      bad += sbad;
+    }
     printf("verify vs 128x128 kernel: %zu mismatching elements%s\n", bad, bad ? "  <-- FAIL" : " (bit-identical)");
     CK(hipMemset(x, 0, xe * 4));
   }

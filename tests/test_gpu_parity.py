@@ -320,6 +320,27 @@ def test_eval_chunking_is_exact_and_stage1_packing_is_bit_identical(gpu):
     assert torch.equal(ls, lc)
 
 
+def test_stage1_scores_do_not_depend_on_the_gemm_kernel_a_launch_is_routed_to(gpu):
+    """A stage-1 launch of >= 4096 rows runs fc1 on the persistent 256x256 kernel (several tiles per workgroup), a
+    smaller one on the 128x128 kernel; both form every partial sum of squares in the same order, so the scores of a
+    sample must be the same bits either way.  8 batches of 16 ViT-Ti/16 images: one batch per launch (3152 rows)
+    against all eight in one launch (8 slabs, 26624 rows, 312 tiles on 256 CUs), both score sites."""
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=11, std=0.05, eps=1e-6, bias_std=0.02)
+    g = torch.Generator().manual_seed(21)
+    batches = [{"pixel_values": torch.randn(16, 3, 224, 224, generator=g)} for _ in range(8)]
+    eng = VitEngine(w, max_images=128)
+    d_ints = [768] * 12
+    for site in ("pre_gelu", "post_gelu"):
+        small = core.stage1_scores(eng, batches, d_ints, site, chunk_images=16)
+        big = core.stage1_scores(eng, batches, d_ints, site, chunk_images=128)
+        for x, y in zip(small, big):
+            assert torch.equal(x, y)
+        assert all(bool(torch.isfinite(x).all()) and float(x.min()) > 0 for x in big)
+
+
 def test_slab_layout_small_token_model_unfused_path(gpu):
     """The 5-token smoke geometry scores through the standalone L2 kernel (no fused epilogue below 128 tokens); the
     slab layout must give the same bits there too, including a ragged last batch."""
