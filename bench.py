@@ -210,7 +210,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"ViT-B/16 ({args.model}), {args.calib} calib images/GPU, full 2SSP @ {args.target} "
+            "config": {"workload": f"{args.model}, {args.calib} calib images/GPU, full 2SSP @ {args.target} "
                                    f"(K={plan.blocks_to_prune} blocks, t={plan.per_block_neurons_to_prune} neurons), "
                                    f"one-shot depth search over {n_eval} eval images/GPU, batch {args.batch}",
                        "weights": "random-init trunc-normal(0.02), fc1 rows log-uniform x[1/4,4], seed 0",
