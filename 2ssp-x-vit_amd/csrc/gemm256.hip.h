@@ -34,14 +34,21 @@
 #define RSTAMP(slot) do {} while (0)
 #endif
 
-// Cache policy of the streamed traffic (activation panel, x tile, outputs).  GEMM_NT=1 marks it non-temporal so that
-// it cannot evict the weight panels from the XCD's 4 MiB L2.  Measured (gemm_bench + rocprofv3 PMC, 63040-row shapes):
-// QKV's HBM-side fetch halves (182 -> 99 MB per launch, L2 hit rate 72 -> 79 %) and yet every shape runs 5-9 % SLOWER,
-// so the default policy stays; the switch is kept for A/B runs only.
+// Cache policy of the streamed traffic (activation panel, x tile, outputs).  GEMM_NT = 1 marks all of it non-temporal
+// so that it cannot evict the weight panels from the XCD's 4 MiB L2; 2 = the LDS-DMA loads only, 3 = the stores only.
+// Measured (gemm_bench + rocprofv3 PMC, 63040-row shapes, interleaved runs): with NT loads QKV's HBM-side fetch halves
+// (182 -> 99 MB per launch, L2 hit rate 72 -> 79 %) and yet every shape runs 5-9 % SLOWER; NT stores alone are within
+// noise of the default.  The default policy stays; the switch is kept for A/B runs only.
 #ifndef GEMM_NT
 #define GEMM_NT 0
 #endif
-#if GEMM_NT
+#if GEMM_NT == 2
+#define GLDS_A glds16_nt
+#define ST_OUT(p, v) (*(p) = (v))
+#elif GEMM_NT == 3
+#define GLDS_A glds16
+#define ST_OUT(p, v) __builtin_nontemporal_store((v), (p))
+#elif GEMM_NT
 #define GLDS_A glds16_nt
 #define ST_OUT(p, v) __builtin_nontemporal_store((v), (p))
 #else
