@@ -403,64 +403,85 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       }
       // full path: the last 8 operations of this wave are the second pass's stores; the next main loop starts behind
       // vmcnt(4), i.e. it waits for everything but the youngest four of them
-    } else {   // EPI_RESID: x += float(bf16(acc + bias)), the fp32 x tile moves through LDS by DMA
-      // block p = (a, b): 32 rows x 32 fp32 columns = 4 KiB, two buffers.  LDS image [32][128 B]; the 16-byte chunk c
-      // of row r sits at chunk c ^ ((r >> 1) & 7) (swizzle applied on the DMA's source address and on the
-      // fragment-shaped accesses; conflict-free ds_read_b128).
+    } else {   // EPI_RESID: x += float(bf16(acc + bias))
+      // The fp32 x tile makes this epilogue a memory-latency problem: 32 KiB per wave must come in and go out.  All the
+      // loads that fit in registers go out AT ONCE, coalesced (a block p = (a, b) of 32 rows x 32 fp32 columns is 4
+      // loads of 8 rows x 128 B: lane -> row 8j + dr, 16-byte chunk le & 7), NXB = 4 blocks = 64 VGPRs (the fragment
+      // and bias registers are dead by then), block p + 4 as soon as block p has been stored.
+      // The accumulators meet that layout through a wave-private LDS buffer: written fragment-shaped (lane -> row
+      // l31, chunk 2q + lh, swizzled by (row >> 1) & 7: conflict-free), read back row-contiguous.
+      // (Round-1 form: two x blocks in flight per wave through LDS-DMA; every pass then waited ~2.3 k cycles for
+      // its block, 20.7 k cycles per tile.)
+      constexpr int NXB = 4;
       if (wave_cols_ok) {
-        const int dr = le >> 3;                                      // row inside an 8-row DMA piece
+        const int dr = le >> 3, cc = le & 7;
         float* const xw = g.x + (size_t)row0 * g.ldx + col0;         // wave's 128 x 64 window of x
-        // DMA piece j of a block covers rows 8j .. 8j+7: lane -> (row 8j + dr, LDS chunk le & 7), which holds the
-        // global chunk (le & 7) ^ ((row >> 1) & 7) = c0 ^ 4*(j & 1) with c0 = (le & 7) ^ (dr >> 1)
-        const uint32_t c0 = (uint32_t)((le & 7) ^ (dr >> 1));
-        uint32_t lane_off[2];                                        // element offset inside the block, j even / odd
-        lane_off[0] = (uint32_t)dr * (uint32_t)g.ldx + (c0 << 2);
-        lane_off[1] = (uint32_t)dr * (uint32_t)g.ldx + ((c0 ^ 4u) << 2);
-        const int lim = g.M - 1 - row0;                              // last valid row of the window (edge tiles)
-        auto xptr = [&](int a, int b, int j) -> float* {
-          if (full) return xw + (size_t)((a * 32 + 8 * j) * g.ldx + b * 32) + lane_off[j & 1];
-          int m = a * 32 + 8 * j + dr; m = m < lim ? m : lim;        // clamp: rows past M are read, never stored
-          return xw + (size_t)m * g.ldx + b * 32 + ((c0 ^ ((j & 1) << 2)) << 2);
-        };
-        auto xdma = [&](int p) {
-          const int a = p >> 1, b = p & 1;
+        // bias + bf16 rounding in place first (frees the 32 bias registers before the x registers are taken)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) GLDS_A(xptr(a, b, j), stg + (p & 1) * 4096 + j * 1024);
-        };
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t p0 = pack_bf16x2(acc[a][b][4 * q] + bb[b][q][0], acc[a][b][4 * q + 1] + bb[b][q][1]);
+              const uint32_t p1 = pack_bf16x2(acc[a][b][4 * q + 2] + bb[b][q][2], acc[a][b][4 * q + 3] + bb[b][q][3]);
+              acc[a][b][4 * q] = bf16lo_f32(p0); acc[a][b][4 * q + 1] = bf16hi_f32(p0);
+              acc[a][b][4 * q + 2] = bf16lo_f32(p1); acc[a][b][4 * q + 3] = bf16hi_f32(p1);
+            }
         char* const cell_lane = stg + l31e * 128;
         const int csw = (l31e >> 1) & 7;
-        xdma(0);
-        xdma(1);
+        const char* const rd_lane = stg + dr * 128;                  // + j*1024 + swizzled chunk (rows 8j + dr)
+        // x is addressed as a raw buffer: SGPR descriptor + SGPR block offset + ONE per-lane VGPR offset, so the 16
+        // loads in flight and their 16 stores need no 64-bit address registers (32 VGPRs the allocator does not
+        // have here).  Rows past M get a per-lane offset beyond the buffer's range (the range check sees the VGPR
+        // offset): their loads return 0 and their stores are dropped by the hardware — edge tiles take the same
+        // straight-line code, no branches, no exec masks.
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(g.x, 0, 0x7ffffff0, 0x00020000);
+        const int lane_off = (dr * g.ldx + cc * 4) * 4;              // bytes: row dr of a piece, 16-byte chunk cc
+        auto xoff = [&](int a, int b, int j) -> int {                // bytes, wave-uniform
+          return ((row0 + a * 32 + 8 * j) * g.ldx + col0 + b * 32) * 4;
+        };
+        const int rows_left = g.M - row0 - dr;                       // row a*32 + 8j + dr is valid iff a*32 + 8j < rows_left
+        auto voff = [&](int a, int j) -> int { return (a * 32 + 8 * j < rows_left) ? lane_off : 0x7fffffff; };
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        f32x4 xin[NXB][4];
+#pragma unroll
+        for (int p = 0; p < NXB; ++p)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            xin[p][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff(p >> 1, j), xoff(p >> 1, p & 1, j), 0));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
           const int a = p >> 1, b = p & 1;
-          // X(p) has landed: younger than it are S(p-1) and X(p+1).  (Touching the lines of blocks 2..7 ahead of
-          // their DMAs — one global_load_dword per 128-byte line at the start of the epilogue — was tried and made
-          // proj / fc2 3-7 % slower: the path is short of memory-level parallelism, not of L2 locality.)
-          if (!full) WAITV(0);
-          else if (p == 0 || p == 7) WAITV(4);
-          else WAITV(8);
+          const int buf = (p & 1) * 4096;                            // two buffers: block p+1 is written while p's reads land
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            f32x4* cell = (f32x4*)(cell_lane + (p & 1) * 4096 + (((2 * q + lhe) ^ csw) << 4));
-            f32x4 xv = *cell;
-            const uint32_t p0 = pack_bf16x2(acc[a][b][4 * q] + bb[b][q][0], acc[a][b][4 * q + 1] + bb[b][q][1]);
-            const uint32_t p1 = pack_bf16x2(acc[a][b][4 * q + 2] + bb[b][q][2], acc[a][b][4 * q + 3] + bb[b][q][3]);
-            xv.x += bf16lo_f32(p0); xv.y += bf16hi_f32(p0); xv.z += bf16lo_f32(p1); xv.w += bf16hi_f32(p1);
-            *cell = xv;
+            f32x4 v; v.x = acc[a][b][4 * q]; v.y = acc[a][b][4 * q + 1]; v.z = acc[a][b][4 * q + 2]; v.w = acc[a][b][4 * q + 3];
+            *(f32x4*)(cell_lane + buf + (((2 * q + lhe) ^ csw) << 4)) = v;
           }
           WAITL0();
           f32x4 v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = *(const f32x4*)(stg + (p & 1) * 4096 + j * 1024 + le * 16);
+          for (int j = 0; j < 4; ++j) v[j] = *(const f32x4*)(rd_lane + buf + j * 1024 + ((cc ^ (((8 * j + dr) >> 1) & 7)) << 4));
           WAITL0();
+          // all four sums first, into four different register quads, THEN the four stores: when hipcc re-used one quad
+          // (add, store, add, store, ...) the last dword of the 16-byte store data came out overwritten by the next
+          // add on lanes 12-15 / 28-31 / 44-47 / 60-63 — a store-data hazard it does not pad on gfx950
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float* dst = xptr(a, b, j);
-            if (full) ST_OUT((f32x4*)dst, v[j]);
-            else if (row0 + a * 32 + 8 * j + dr < g.M) ST_OUT((f32x4*)dst, v[j]);
+          for (int j = 0; j < 4; ++j) v[j] += xin[p % NXB][j];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), xr, voff(a, j), xoff(a, b, j), 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (p + NXB < 8) {                   // block p + NXB takes the registers of block p (pinned: hipcc would
+            __builtin_amdgcn_sched_barrier(0); // hoist these loads to the top and spill their destinations)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              xin[p % NXB][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff((p + NXB) >> 1, j), xoff((p + NXB) >> 1, (p + NXB) & 1, j), 0));
+            __builtin_amdgcn_sched_barrier(0);
           }
-          if (p + 2 < 8) xdma(p + 2);          // buffer p&1 is free: its read-out has landed in registers
         }
       }
     }

@@ -84,7 +84,7 @@ int main(int argc, char** argv) {
     run(); CK(hipStreamSynchronize(s));
     size_t bad = 0;
     if (resid) { std::vector<float> xn(xe); CK(hipMemcpy(xn.data(), x, xe * 4, hipMemcpyDeviceToHost));
-                 for (size_t i = 0; i < (size_t)M * Npad; ++i) { size_t rr = i / Npad, cc = i % Npad; if ((int)cc < N && memcmp(&xn[rr * Npad + cc], &xr[rr * Npad + cc], 4)) ++bad; } }
+                 for (size_t i = 0; i < (size_t)M * Npad; ++i) { size_t rr = i / Npad, cc = i % Npad; if ((int)cc < N && memcmp(&xn[rr * Npad + cc], &xr[rr * Npad + cc], 4)) { if (bad < 16) printf("  x[%zu][%zu] = %.9g vs ref %.9g\n", rr, cc, xn[rr * Npad + cc], xr[rr * Npad + cc]); ++bad; } } }
     else { std::vector<uint16_t> on(oe); CK(hipMemcpy(on.data(), out, oe * 2, hipMemcpyDeviceToHost));
            for (size_t i = 0; i < oe; ++i) { if ((int)(i % Npad) < N && on[i] != orf[i]) ++bad; } }
     if (sc1 || sc2) {
@@ -93,6 +93,19 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < se; ++i) { if ((int)(i % Npad) < N) { if (memcmp(&sn[i], &slab_ref[i], 4)) { if (sbad < 12) printf("  slab[tile %zu seg %zu col %zu] = %.9g vs ref %.9g\n", i / Npad / 2, (i / Npad) % 2, i % Npad, sn[i], slab_ref[i]); ++sbad; } ssum += sn[i]; } }
       printf("score slab vs 128x128 kernel: %zu mismatching of %zu (sum %.6g)%s\n", sbad, se, ssum, sbad ? "  <-- FAIL" : " (bit-identical)");
       bad += sbad;
+    }
+    if (resid) {   // rows past M must stay untouched (x is allocated with a few spare rows, zeroed above)
+      std::vector<float> xt(xe); CK(hipMemcpy(xt.data(), x, xe * 4, hipMemcpyDeviceToHost));
+      size_t spill = 0; for (size_t i = (size_t)M * Npad; i < xe; ++i) if (xt[i] != 0.f) ++spill;
+      if (spill) { printf("  %zu elements written past row M  <-- FAIL\n", spill); bad += spill; }
+    }
+    if (resid && bad) {
+      std::vector<float> xn(xe); CK(hipMemcpy(xn.data(), x, xe * 4, hipMemcpyDeviceToHost));
+      std::vector<long> hc(64, 0), hr(128, 0), ht(16, 0);
+      for (size_t i = 0; i < (size_t)M * Npad; ++i) { size_t rr = i / Npad, cc = i % Npad; if ((int)cc < N && memcmp(&xn[i], &xr[i], 4)) { ++hc[cc % 64]; ++hr[rr % 128]; ++ht[(rr / 256) % 16]; } }
+      printf("  mismatches by column %% 64:"); for (int i = 0; i < 64; ++i) if (hc[i]) printf(" %d:%ld", i, hc[i]); printf("\n");
+      printf("  mismatches by row %% 128:"); for (int i = 0; i < 128; ++i) if (hr[i]) printf(" %d:%ld", i, hr[i]); printf("\n");
+      printf("  mismatches by (row / 256) %% 16:"); for (int i = 0; i < 16; ++i) printf(" %ld", ht[i]); printf("\n");
     }
     printf("verify vs 128x128 kernel: %zu mismatching elements%s\n", bad, bad ? "  <-- FAIL" : " (bit-identical)");
     CK(hipMemset(x, 0, xe * 4));
