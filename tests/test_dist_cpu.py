@@ -138,3 +138,27 @@ def test_gather_is_identity_without_process_group():
     out = D.gather_batch_vectors(v, 3)
     assert [float(t[0, 0]) for t in out] == [0.0, 1.0, 2.0]
     assert D.world() == (0, 1) and D.owns(3, 0, 1)
+
+
+def test_eval_chunks_cut_the_image_stream_exactly_and_counts_do_not_move():
+    """core._chunks re-cuts the owned batches into forwards of exactly `chunk_images` images (batches are split and
+    joined as needed); integer results must not depend on where the cuts fall."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import core
+    w, batches = _batches()
+    eng = OracleBackedEngine(build_from_flat(w, "timm"))
+    sizes = [int(px.shape[0]) for _, px, _ in core._chunks(eng, batches, None, False, "t", 0, 1, 5)]
+    assert sizes == [5, 5, 5, 4]                                # 4+4+4+4+3 images re-cut
+    assert [int(px.shape[0]) for _, px, _ in core._chunks(eng, batches, 2, False, "t", 0, 1, 64)] == [8]
+    ref = core.depth_search_counts(eng, batches, eng.depth, batch_limit=None, chunk_images=64)
+    for c in (1, 3, 5, 7, 19):
+        assert core.depth_search_counts(eng, batches, eng.depth, batch_limit=None, chunk_images=c) == ref
+        assert core.top1_counts(eng, batches, chunk_images=c) == core.top1_counts(eng, batches, chunk_images=64)
+
+
+def test_best_eval_chunk_prefers_full_rounds_of_the_persistent_gemm():
+    from ssp2vit.core import best_eval_chunk
+    n = best_eval_chunk(197, 320)
+    rows = -(-n * 197 // 256)
+    assert 16 <= n <= 320 and (rows * 3) % 256 <= 8 or (rows * 3) % 256 >= 240 or rows * 3 <= 256   # ~whole rounds of 256 CUs
+    assert best_eval_chunk(197, 8) == 8                          # cap below the search range: the cap itself
