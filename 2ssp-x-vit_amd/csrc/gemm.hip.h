@@ -81,9 +81,15 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 //   * gelu(x) = max(x, 0) - |x| * h  with  h = erfc(|z|)/2: one fma instead of compare + select + multiply, and one
 //     rounding less than x * (1 - h)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
-  f32x2 u;
-  u.x = fabsf(x.x) * 0.84932180028801904272f; u.y = fabsf(x.y) * 0.84932180028801904272f;
+// max(x, 0) as ONE instruction (fmaxf costs two: hipcc canonicalises the operand with v_max_f32 x, x first)
+__device__ __forceinline__ float relu_f32(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+// x and ax = |x| are passed separately: on the fc1 paths both come straight out of the packed bf16 pair
+__device__ __forceinline__ f32x2 gelu_erf_core(f32x2 x, f32x2 ax) {
+  const f32x2 u = ax * 0.84932180028801904272f;
   f32x2 d = u * 0.27273748087922250f + 1.0f, t;               // 0.3275911 / sqrt(log2 e)
   t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
   f32x2 p = t * 0.5307027145f + -0.7265760135f;               // A&S 7.1.26 coefficients, halved
@@ -95,10 +101,21 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
   f32x2 e;
   e.x = __builtin_amdgcn_exp2f(-a.x); e.y = __builtin_amdgcn_exp2f(-a.y);
   const f32x2 h = p * e;                                      // erfc(|z|) / 2
-  f32x2 r;
-  r.x = fmaf(-fabsf(x.x), h.x, fmaxf(x.x, 0.f));
-  r.y = fmaf(-fabsf(x.y), h.y, fmaxf(x.y, 0.f));
-  return r;
+  f32x2 rl;
+  rl.x = relu_f32(x.x); rl.y = relu_f32(x.y);
+  return -ax * h + rl;                                        // one v_pk_fma_f32 (neg modifier)
+}
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+  f32x2 ax; ax.x = fabsf(x.x); ax.y = fabsf(x.y);
+  return gelu_erf_core(x, ax);
+}
+// GELU of a packed bf16 pair (lo | hi << 16): four bit operations unpack the two values AND their magnitudes
+__device__ __forceinline__ f32x2 gelu_erf_pk(uint32_t pk, f32x2& pre) {
+  const uint32_t lo = pk << 16;
+  pre.x = __builtin_bit_cast(float, lo); pre.y = __builtin_bit_cast(float, pk & 0xffff0000u);
+  f32x2 ax;
+  ax.x = __builtin_bit_cast(float, lo & 0x7fffffffu); ax.y = __builtin_bit_cast(float, pk & 0x7fff0000u);
+  return gelu_erf_core(pre, ax);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   bf16x2 v; v[0] = (bf16)lo; v[1] = (bf16)hi;     // one v_cvt_pk_bf16_f32
@@ -298,8 +315,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
             o = pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias);
           } else {
             const uint32_t pk = pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias);
-            f32x2 pre; pre.x = bf16lo_f32(pk); pre.y = bf16hi_f32(pk);
-            const f32x2 gl = gelu_erf_fast2(pre);
+            f32x2 pre;
+            const f32x2 gl = gelu_erf_pk(pk, pre);
             o = pack_bf16x2(gl.x, gl.y);
             if (keep_pre) { acc[a][b][i] = pre.x; acc[a][b][i + 1] = pre.y; }   // second staging pass below
             if (SCORE) {

@@ -316,8 +316,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             for (int i = 0; i < 16; i += 2) {
               const int rw = a2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * lhe;     // row inside the 64-row pass (i even: rw, rw+1)
               const uint32_t pk = pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias);
-              f32x2 pre; pre.x = bf16lo_f32(pk); pre.y = bf16hi_f32(pk);
-              const f32x2 gl = gelu_erf_fast2(pre);
+              f32x2 pre;
+              const f32x2 gl = gelu_erf_pk(pk, pre);
               const uint32_t o = pack_bf16x2(gl.x, gl.y);
               f32x2 sv = pre;
               if (SCORE == 2) { sv.x = bf16lo_f32(o); sv.y = bf16hi_f32(o); }
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
                 for (int p = 0; p < 2; ++p) {
                   pk[p] = pack_bf16x2(acc[a][b][4 * q + 2 * p] + bb[b][q][2 * p], acc[a][b][4 * q + 2 * p + 1] + bb[b][q][2 * p + 1]);
                   if (EPI == EPI_FC1) {
-                    f32x2 pre; pre.x = bf16lo_f32(pk[p]); pre.y = bf16hi_f32(pk[p]);
-                    const f32x2 gl = gelu_erf_fast2(pre);
+                    f32x2 pre;
+                    const f32x2 gl = gelu_erf_pk(pk[p], pre);
                     pk[p] = pack_bf16x2(gl.x, gl.y);
                   }
                 }
