@@ -71,13 +71,17 @@ class _Chunker:
 @torch.no_grad()
 def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch_limit: Optional[int] = None,
                   progress: bool = False, score_chain: str = "fp32", process_group=None,
-                  chunk_images: Optional[int] = None) -> List[torch.Tensor]:
+                  chunk_images: Optional[int] = None, defer: bool = False):
     """Reference src/vit_pruning.py:111-201.  `engine`: VitEngine or callable(min_images) -> VitEngine.
 
     Several dataloader batches share one forward (`chunk_images`, default SSP2_CHUNK_IMAGES).  A sample's sum of
     squares is folded per 128-row GEMM tile, so its fp32 rounding depends on where the sample sits relative to the
     tile grid; every batch is therefore laid out as its own 256-row-aligned slab (ssp2_rows / RowMap), which pins
-    that position: scores are bit-identical for every packing and every world size."""
+    that position: scores are bit-identical for every packing and every world size.
+
+    `defer=True` (fp32 chain) returns a zero-argument callable instead of the list: all device work is enqueued, the
+    device-to-host copy and the wait happen when it is called — a caller can enqueue stage 2 first and run its host
+    mask step while the GPU works (bench.py does)."""
     rank, ws = _dist.world(process_group)
     chunk_images = DEFAULT_CHUNK_IMAGES if chunk_images is None else chunk_images
     local: List[Tuple[int, torch.Tensor]] = []
@@ -111,13 +115,35 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
     vecs = _dist.gather_batch_vectors(local, n_batches, process_group)
     denom = max(1, n_samples)
     if not vecs:
-        return [torch.zeros(d) for d in d_ints]
+        empty = [torch.zeros(d) for d in d_ints]
+        return (lambda: empty) if defer else empty
     if score_chain == "fp32":
         total = torch.zeros_like(vecs[0])
         for v in vecs:                          # global batch order: identical on every rank / world size / chunking
             total += v
-        total = (total / denom).to("cpu")
-        return [total[l, :d].clone() for l, d in enumerate(d_ints)]
+        total = total / denom
+        if defer and total.is_cuda:
+            # the copy rides a side stream behind an event recorded HERE, so that waiting for the scores does not wait
+            # for whatever the caller enqueues on the compute stream afterwards (stage 2)
+            main = torch.cuda.current_stream(total.device)
+            side = torch.cuda.Stream(total.device)
+            host = torch.empty(total.shape, dtype=total.dtype, pin_memory=True)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                host.copy_(total, non_blocking=True)
+                total.record_stream(side)
+                done = torch.cuda.Event()
+                done.record(side)
+
+            def finish_async():
+                done.synchronize()
+                return [host[l, :d].clone() for l, d in enumerate(d_ints)]
+            return finish_async
+
+        def finish():
+            host = total.to("cpu")
+            return [host[l, :d].clone() for l, d in enumerate(d_ints)]
+        return finish if defer else finish()
     # bf16_ref: the cross-batch `+=` and the final division happen in bf16 exactly as reference :154-157, :200
     host = [v.to("cpu") for v in vecs]
     imps: List[torch.Tensor] = []
@@ -198,9 +224,10 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
         eng.layers(x, n, 0, eng.depth - 1, attn_skip)
         eng.tail(x, n, attn_skip, labels=labels, correct=correct_dev)      # last block + head on the CLS rows
         total += n
-    counts = torch.tensor([0, total], dtype=torch.int64, device=correct_dev.device if correct_dev is not None else "cpu")
-    if correct_dev is not None:
-        counts[0] = correct_dev[0]
+    if correct_dev is not None:       # (no host list -> device tensor here: that H2D copy would wait for the stream)
+        counts = torch.cat([correct_dev, torch.full((1,), total, dtype=torch.int64, device=correct_dev.device)])
+    else:
+        counts = torch.tensor([0, total], dtype=torch.int64)
     if ws > 1 or (_dist.FORCE_COLLECTIVES and _dist._initialised()):
         counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
     c = counts.to("cpu")
@@ -210,7 +237,7 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
 @torch.no_grad()
 def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional[int] = 5, process_group=None,
                         removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None,
-                        chunk_images: Optional[int] = None):
+                        chunk_images: Optional[int] = None, defer: bool = False):
     """One pass over the eval batches that yields the baseline AND every candidate's correct-count.
 
     The reference deep-copies the model and re-runs the whole forward per candidate (mask_conjunction.py:339-355,
@@ -218,7 +245,8 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
     forward, and candidate i (attention of block i bypassed) restarts from the cached input of block i: blocks
     0..i-1 are bit-identical to the baseline, so the result equals a full re-run while executing
     L(L+1)/2 + L block passes per batch instead of L(L+1).
-    Returns (baseline_correct, [candidate_correct per block], total)."""
+    Returns (baseline_correct, [candidate_correct per block], total); with `defer=True` a zero-argument callable
+    that waits for the device and returns that tuple."""
     rank, ws = _dist.world(process_group)
     L = depth
     counts_dev = None
@@ -249,11 +277,16 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
     if counts_dev is None:
         counts = torch.zeros(L + 2, dtype=torch.int64)
     else:
-        counts = torch.cat([counts_dev, torch.tensor([total], dtype=torch.int64, device=counts_dev.device)])
+        # torch.full, not torch.tensor([...], device=...): a host list becomes a pageable H2D copy, which makes the host
+        # wait for everything enqueued before it (the whole search)
+        counts = torch.cat([counts_dev, torch.full((1,), total, dtype=torch.int64, device=counts_dev.device)])
     if ws > 1 or (_dist.FORCE_COLLECTIVES and _dist._initialised()):
         counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
-    c = counts.to("cpu").tolist()
-    return c[-2], c[:-2], c[-1]
+
+    def finish():
+        c = counts.to("cpu").tolist()
+        return c[-2], c[:-2], c[-1]
+    return finish if defer else finish()
 
 
 def impacts_from_counts(base: int, cand: Sequence[int], total: int) -> List[float]:

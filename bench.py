@@ -154,17 +154,21 @@ def main():
     n_eval = args.eval_batches * args.batch
 
     def step():
-        imps = core.stage1_scores(eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
-                                  chunk_images=args.calib_chunk)
-        base, cand, total = core.depth_search_counts(eng, eval_loader, depth, batch_limit=None, process_group=pg,
-                                                     chunk_images=args.eval_chunk or n_eval)
-        impact = torch.tensor(core.impacts_from_counts(base, cand, total), dtype=torch.float32)
+        # both stages are enqueued before the host waits for either: the a7 mask step runs on the CPU while the GPU
+        # is still searching (the two stages are independent: stage 2 evaluates the dense model)
+        scores = core.stage1_scores(eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
+                                    chunk_images=args.calib_chunk, defer=True)
+        search = core.depth_search_counts(eng, eval_loader, depth, batch_limit=None, process_group=pg,
+                                          chunk_images=args.eval_chunk or n_eval, defer=True)
+        imps = scores()
         masks = []
         t = plan.per_block_neurons_to_prune
         for imp in imps:                                              # a7 mask step (host, 12 x 3072)
             keep, _ = torch.sort(torch.argsort(imp, descending=True)[: imp.numel() - t])
             m = torch.ones(imp.numel(), dtype=torch.int16); m[keep] = 0
             masks.append(m)
+        base, cand, total = search()
+        impact = torch.tensor(core.impacts_from_counts(base, cand, total), dtype=torch.float32)
         blocks = sorted(int(i) for i in torch.argsort(impact)[: plan.blocks_to_prune])   # a9 (auto_2ssp.py:857)
         return imps, impact, masks, blocks
 

@@ -162,3 +162,22 @@ def test_best_eval_chunk_prefers_full_rounds_of_the_persistent_gemm():
     rows = -(-n * 197 // 256)
     assert 16 <= n <= 320 and (rows * 3) % 256 <= 8 or (rows * 3) % 256 >= 240 or rows * 3 <= 256   # ~whole rounds of 256 CUs
     assert best_eval_chunk(197, 8) == 8                          # cap below the search range: the cap itself
+
+
+def test_deferred_results_equal_immediate_ones():
+    """defer=True only postpones the device-to-host copy and the wait (bench.py enqueues stage 2 before it waits for
+    stage 1): same values."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import core
+    w, batches = _batches()
+    model = build_from_flat(w, "timm")
+    eng = OracleBackedEngine(model)
+    d_ints = [b.mlp.fc1.out_features for b in model.blocks]
+    now = core.stage1_scores(eng, batches, d_ints, "pre_gelu")
+    later = core.stage1_scores(eng, batches, d_ints, "pre_gelu", defer=True)
+    assert callable(later)
+    for a, b in zip(now, later()):
+        assert torch.equal(a, b)
+    assert core.depth_search_counts(eng, batches, eng.depth, batch_limit=None, defer=True)() == \
+        core.depth_search_counts(eng, batches, eng.depth, batch_limit=None)
+    assert [float(t.sum()) for t in core.stage1_scores(eng, [], d_ints, "pre_gelu", defer=True)()] == [0.0] * len(d_ints)
