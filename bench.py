@@ -228,7 +228,7 @@ def main():
             # dominant kernel family: fc1 (+bias +erf-GELU; + fused activation-L2 partials in stage 1).
             # achieved = algorithmic flops (2*M*N*K summed over the recorded launches) / summed HIP-event durations.
             ach = prof.flops / (prof.total_ms * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "fc1 GEMM family: gemm_bf16_kernel<EPI_FC1,score> 128x128 (stage 1, fused L2 partials) + gemm256_bf16_kernel<EPI_FC1> 256x256 persistent (search passes); bias + erf-GELU fused",
+            line["roofline"] = {"bound": "mfma", "kernel": "fc1 GEMM family: gemm256_bf16_kernel<EPI_FC1,SCORE> persistent 256x256 (stage 1: + fused activation-L2 partials; search passes: SCORE=0) and gemm_bf16_kernel<EPI_FC1> 128x128 (CLS tail); bias + erf-GELU fused",
                                 "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
