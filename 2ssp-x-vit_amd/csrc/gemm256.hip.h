@@ -96,9 +96,13 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) t16[k] = ((2 * k + lh) ^ ((l31 >> 1) & 7)) << 4;
 
-  // per-lane source of the wave's 4 LDS-DMA pieces per operand, as 32-bit element offsets from g.A / g.W (eight
-  // VGPRs instead of sixteen: the kernel lives at the 256-register limit)
+  // per-lane source of the wave's 4 LDS-DMA pieces per operand, as 32-bit BYTE offsets from g.A / g.W: the pieces are
+  // issued as global_load_lds with an SGPR base (operand + K offset, scalar arithmetic) and this VGPR offset, so a
+  // piece between two MFMAs costs no vector instruction besides itself
   uint32_t a_src[4], w_src[4];
+  // what a wave carries in the first / second half of a K-tile (see the main loop): g0 B then A, g1 A then B
+  const char* const ride_base0 = (const char*)(wm ? g.A : g.W);
+  const char* const ride_base1 = (const char*)(wm ? g.W : g.A);
   int m0 = 0, n0 = 0;
   float bias_next = 0.f;                                // bias[n0 + wn*64 + lane] of the tile being prefetched
   auto set_tile = [&](int tile) {
@@ -109,12 +113,12 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       const int row = (wave + 8 * i) * 8 + (lane >> 3);
       const int c_src = (lane & 7) ^ ((row >> 1) & 7);
       int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
-      a_src[i] = (uint32_t)gr * (uint32_t)g.lda + c_src * 8;
-      w_src[i] = (uint32_t)(n0 + row) * (uint32_t)g.ldw + c_src * 8;
+      a_src[i] = ((uint32_t)gr * (uint32_t)g.lda + c_src * 8) * 2;
+      w_src[i] = ((uint32_t)(n0 + row) * (uint32_t)g.ldw + c_src * 8) * 2;
     }
   };
-  auto piece_a = [&](int off, int kt, int i) { GLDS_A(g.A + (a_src[i] + kt * GEMM_BK), smem + off + (wave + 8 * i) * 1024); };
-  auto piece_b = [&](int off, int kt, int i) { glds16(g.W + (w_src[i] + kt * GEMM_BK), smem + off + (wave + 8 * i) * 1024); };
+  auto piece_a = [&](int off, int kt, int i) { GLDS_A((const char*)g.A + (size_t)kt * (GEMM_BK * 2) + a_src[i], smem + off + (wave + 8 * i) * 1024); };
+  auto piece_b = [&](int off, int kt, int i) { glds16((const char*)g.W + (size_t)kt * (GEMM_BK * 2) + w_src[i], smem + off + (wave + 8 * i) * 1024); };
   auto stage_a = [&](int off, int kt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_a(off, kt, i);
@@ -167,6 +171,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     // counted wait retires its B(kt+1) and A(kt+1) pieces one barrier before their first read (phase 4kt+4).
     bf16x8 fa[2][C::TM], fb[2][C::TN];
     int sa = C::A0, sb = C::B0;
+    uint32_t ride0[4], ride1[4];                               // the pieces carried in half 0 / half 1 (selected once per tile)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ride0[i] = wm ? a_src[i] : w_src[i]; ride1[i] = wm ? w_src[i] : a_src[i]; }
     if (wm) {                                                  // phase 0 of the tile: g1 has no unit to compute yet
       if (nk > 1) stage_b(C::B1, 1);                           // its B(1) pieces (B1 is free: the tile-start barrier)
       asm volatile("s_barrier" ::: "memory");                  // the skew
@@ -209,12 +216,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         //   half 1: g0 carries A(kt+2) -> sa2, g1 carries B(kt+2) -> sb (K-tile kt's slot: its reads ended a barrier ago)
         const bool take_a = (half == 0) == (wm != 0);
         const bool dma_on = (half == 0 && !wm) ? b_on : a_on;
-        const bf16* const dbase = take_a ? g.A : g.W;
-        const int dkoff = ((half == 0 && !wm) ? kt + 1 : kt + 2) * GEMM_BK;
+        const char* const dbase = (half == 0 ? ride_base0 : ride_base1)                      // wave-uniform: SGPRs
+                                  + (size_t)(((half == 0 && !wm) ? kt + 1 : kt + 2) * (GEMM_BK * 2));
         const int dlds = take_a ? sa2 : (half == 0 ? sb1 : sb);
-        uint32_t dsrc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dsrc[i] = take_a ? a_src[i] : w_src[i];
+        const uint32_t (&dsrc)[4] = half == 0 ? ride0 : ride1;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -227,8 +232,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             if (pair & 1) {
               __builtin_amdgcn_sched_barrier(0);
               if (dma_on) {
-                if (take_a) GLDS_A(dbase + (dsrc[pair >> 1] + dkoff), smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
-                else        glds16(dbase + (dsrc[pair >> 1] + dkoff), smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
+                if (take_a) GLDS_A(dbase + dsrc[pair >> 1], smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
+                else        glds16(dbase + dsrc[pair >> 1], smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
               }
               __builtin_amdgcn_sched_barrier(0);
             }
