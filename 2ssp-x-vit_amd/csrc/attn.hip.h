@@ -81,6 +81,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       *(bf16x8*)(Vs + key * VSB + (CH + c) * 16) = z;
     }
   }
+  // Q fragments of the wave's first query tile go out while K / V are still in flight; the next tile's are fetched
+  // behind the current tile's QK^T (software pipeline: no query load is ever waited for at the top of a tile)
+  const bf16* qbase = (CLS_ONLY ? qsrc + (size_t)img * q_img_stride : qsrc + img_row * ld) + head * DH;
+  auto load_q = [&](int qt, bf16x8 (&dst)[KS]) {
+    const int q = qt * 32 + l31;
+    const int qc = q < tokens ? q : tokens - 1;
+    const bf16* qp = qbase + (size_t)qc * q_ld + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) dst[s] = *(const bf16x8*)(qp + 16 * s);
+  };
+  bf16x8 qnext[KS];
+  if (wave < (CLS_ONLY ? 1 : NT)) load_q(wave, qnext);
   if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -90,14 +102,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const int v_sw = DMA ? ((tr_q >> 1) & 1) : 0;          // swizzle bit of this lane's V rows (row bit 1 == tr_q bit 1)
   const int k_sw = DMA ? ((l31 >> 1) & 7) : 0;
 
-  const bf16* qbase = (CLS_ONLY ? qsrc + (size_t)img * q_img_stride : qsrc + img_row * ld) + head * DH;
   for (int qt = wave; qt < (CLS_ONLY ? 1 : NT); qt += 4) {   // wave-uniform trip count: EXEC stays full
     const int q = qt * 32 + l31;
-    const int qc = q < tokens ? q : tokens - 1;
-    const bf16* qp = qbase + (size_t)qc * q_ld + 8 * lh;
     bf16x8 qf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+    for (int s = 0; s < KS; ++s) qf[s] = qnext[s];
+    if (!CLS_ONLY && qt + 4 < NT) load_q(qt + 4, qnext);
 
     f32x16 sacc[NT];
 #pragma unroll
