@@ -30,13 +30,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   // 1-KiB piece, every piece of the head in flight at once) and bank conflicts are removed by XOR swizzles applied on
   // the DMA's source address and again on the reads:  K chunk ^= (row >> 1) & 7  (ds_read_b128, lane <-> row),
   // V 64-byte half ^= (row >> 1) & 1  (ds_read_b64_tr_b16: 4 rows x 64 B per 32-lane group).
-  // Other head widths (80: H/14) keep padded rows filled through registers.
-  constexpr bool DMA = (DH == 64);
-  constexpr int KSB = DMA ? 128 : DH * 2 + 16;       // K row stride (bytes): conflict-free ds_read_b128
-  constexpr int VSB = DMA ? 128 : 192;               // V row stride (bytes): 48 dwords -> 4 rows x 16 dwords tile 64 banks
+  // d_h = 80 (H/14): the same lane-linear DMA image with 160-byte rows (10 chunks per row, a piece covers 6.4 rows),
+  // no swizzle: the K reads of rows r and r + 8 and a quarter of the transposed V reads are 2-way bank conflicts, a
+  // small price next to seven serialised global-load round trips of the register-staged fill.  The third 32-column
+  // V^T tile reads 32 bytes past its row (columns 80..95): whatever is there only reaches output rows >= 80, which
+  // are never stored.  Other head widths keep padded rows filled through registers.
+  constexpr bool DMA64 = (DH == 64), DMA80 = (DH == 80 && (NT * 32 * (DH / 8)) % 64 == 0);
+  constexpr bool DMA = DMA64 || DMA80;
+  constexpr int KSB = DMA ? DH * 2 : DH * 2 + 16;    // K row stride (bytes); padded: conflict-free ds_read_b128
+  constexpr int VSB = DMA ? DH * 2 : 192;            // V row stride (bytes); padded: 4 rows x 16 dwords tile 64 banks
   constexpr int NKEY = NT * 32;
   constexpr int CH = DH / 8;
-  static_assert(DT * 32 * 2 <= VSB, "V row does not fit its LDS stride");
+  static_assert(DMA80 || DT * 32 * 2 <= VSB, "V row does not fit its LDS stride");
 
   char* Ks = smem;
   char* Vs = smem + NKEY * KSB;
@@ -47,7 +52,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const bf16* base = qkv + img_row * ld + head * DH;
 
   // ---- stage K, V
-  if constexpr (DMA) {
+  if constexpr (DMA80) {
+    for (int piece = wave; piece < NKEY * CH / 64; piece += 4) {
+      const int gch = piece * 64 + lane, row = gch / CH, c = gch - row * CH;
+      const int rc = row < tokens ? row : tokens - 1;
+      const bf16* rowp = base + (size_t)rc * ld + c * 8;
+      glds16(rowp + dim, Ks + piece * 1024);
+      glds16(rowp + 2 * dim, Vs + piece * 1024);
+    }
+  } else if constexpr (DMA64) {
     // rows past `tokens` copy the last valid row: finite values, masked out of the softmax (p = 0) below
     for (int piece = wave; piece < NKEY / 8; piece += 4) {
       const int row = piece * 8 + (lane >> 3), c = lane & 7;
@@ -71,7 +84,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     *(bf16x8*)(Ks + key * KSB + c * 16) = kv;
     *(bf16x8*)(Vs + key * VSB + c * 16) = vv;
   }
-  if (DT * 32 > DH) {
+  if (!DMA && DT * 32 > DH) {
     constexpr int PC = (DT * 32 - DH) / 8;
     bf16x8 z;
 #pragma unroll
@@ -99,8 +112,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   // per-lane constants of the transposed V read: 16-lane group -> 16 d_h columns, lane 4q+p -> row q, cols 4p..
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
   const int v_lane_off = (4 * lh + tr_q) * VSB + (16 * tr_g + 4 * tr_p) * 2;
-  const int v_sw = DMA ? ((tr_q >> 1) & 1) : 0;          // swizzle bit of this lane's V rows (row bit 1 == tr_q bit 1)
-  const int k_sw = DMA ? ((l31 >> 1) & 7) : 0;
+  const int v_sw = DMA64 ? ((tr_q >> 1) & 1) : 0;        // swizzle bit of this lane's V rows (row bit 1 == tr_q bit 1)
+  const int k_sw = DMA64 ? ((l31 >> 1) & 7) : 0;
 
   for (int qt = wave; qt < (CLS_ONLY ? 1 : NT); qt += 4) {   // wave-uniform trip count: EXEC stays full
     const int q = qt * 32 + l31;
@@ -114,10 +127,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) sacc[kt][i] = 0.f;
-      const char* kp = Ks + (kt * 32 + l31) * KSB + (DMA ? 0 : 16 * lh);
+      const char* kp = Ks + (kt * 32 + l31) * KSB + (DMA64 ? 0 : 16 * lh);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const bf16x8 kf = *(const bf16x8*)(kp + (DMA ? (((2 * s + lh) ^ k_sw) << 4) : 32 * s));
+        const bf16x8 kf = *(const bf16x8*)(kp + (DMA64 ? (((2 * s + lh) ^ k_sw) << 4) : 32 * s));
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
       }
     }
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       }
     }
     // ---- store
-    if constexpr (DMA && !CLS_ONLY) {
+    if constexpr (DMA64 && !CLS_ONLY) {
       // through a wave-private [32 queries][128 B] LDS tile (chunk ^= row & 7), so that every global store is a whole
       // 128-byte row segment of 8 lanes x 16 B instead of 8 bytes per lane at a row stride
       char* ost = smem + 2 * NKEY * 128 + wave * 4096;

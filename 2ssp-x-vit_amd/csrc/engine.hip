@@ -205,7 +205,10 @@ static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const flo
 template <int DH, int NT, bool CLS>
 static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
   // d_h = 64: 128-byte K and V rows (LDS-DMA staging) + 4 KiB per wave of output staging; else padded rows
-  constexpr int smem = DH == 64 ? NT * 32 * 256 + 4 * 4096 : NT * 32 * (DH * 2 + 16) + NT * 32 * 192;
+  // d_h = 80 with a whole number of 1-KiB DMA pieces: 160-byte rows + 64 bytes of slack behind V (attn.hip.h)
+  constexpr int smem = DH == 64 ? NT * 32 * 256 + 4 * 4096
+                     : (DH == 80 && (NT * 32 * 10) % 64 == 0) ? NT * 32 * 320 + 64
+                     : NT * 32 * (DH * 2 + 16) + NT * 32 * 192;
   static bool attr_done = false;
   if (!attr_done) {
     HIPCHK(hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, NT, CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
