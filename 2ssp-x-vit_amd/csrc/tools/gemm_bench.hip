@@ -110,6 +110,22 @@ int main(int argc, char** argv) {
     printf("verify vs 128x128 kernel: %zu mismatching elements%s\n", bad, bad ? "  <-- FAIL" : " (bit-identical)");
     CK(hipMemset(x, 0, xe * 4));
   }
+  if (const char* st = getenv("GEMM_STRESS")) {   // race screen: many launches, every result compared with the first
+    const int reps = atoi(st);
+    const bool resid = (epi % 10) == 1;
+    size_t xe = (size_t)(M + M / 196 + 2) * Npad, oe = (size_t)M * Npad, se = (size_t)((M + 127) / 128) * 2 * Npad;
+    std::vector<float> x0(resid ? xe : 0), xi(resid ? xe : 0), s0(se), si(se); std::vector<uint16_t> o0(resid ? 0 : oe), oi(resid ? 0 : oe);
+    int bad_runs = 0;
+    for (int r = 0; r <= reps; ++r) {
+      CK(hipMemset(x, 0, xe * 4)); CK(hipMemset(out, 0, oe * 2)); CK(hipMemset(slab, 0, se * 4));
+      run(); CK(hipStreamSynchronize(s));
+      if (resid) CK(hipMemcpy((r ? xi : x0).data(), x, xe * 4, hipMemcpyDeviceToHost)); else CK(hipMemcpy((r ? oi : o0).data(), out, oe * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy((r ? si : s0).data(), slab, se * 4, hipMemcpyDeviceToHost));
+      if (r && ((resid ? memcmp(xi.data(), x0.data(), xe * 4) : memcmp(oi.data(), o0.data(), oe * 2)) || memcmp(si.data(), s0.data(), se * 4))) ++bad_runs;
+    }
+    printf("stress: %d of %d launches differ from the first%s\n", bad_runs, reps, bad_runs ? "  <-- FAIL" : " (deterministic)");
+    CK(hipMemset(x, 0, xe * 4));
+  }
   for (int i = 0; i < 3; ++i) run();
   CK(hipStreamSynchronize(s));
   std::vector<float> ms(iters);
