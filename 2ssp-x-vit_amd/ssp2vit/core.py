@@ -112,7 +112,9 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
     if ch is not None and ch.items:
         flush()
 
-    vecs = _dist.gather_batch_vectors(local, n_batches, process_group)
+    ld = max((int(d) + 63) // 64 * 64 for d in d_ints) if d_ints else 0          # = VitEngine.score_ld
+    vecs = _dist.gather_batch_vectors(local, n_batches, process_group,
+                                      shape=(local[0][1].shape if local else (len(d_ints), ld)))
     denom = max(1, n_samples)
     if not vecs:
         empty = [torch.zeros(d) for d in d_ints]

@@ -35,9 +35,12 @@ def owns(batch_index: int, rank: int, world_size: int) -> bool:
     return batch_index % world_size == rank
 
 
-def gather_batch_vectors(local: Sequence[Tuple[int, torch.Tensor]], n_batches_total: int, group=None) -> List[torch.Tensor]:
+def gather_batch_vectors(local: Sequence[Tuple[int, torch.Tensor]], n_batches_total: int, group=None,
+                         shape: Optional[Tuple[int, int]] = None) -> List[torch.Tensor]:
     """local = [(global batch index, tensor [L, ld])] owned by this rank (round-robin ownership).
-    Returns the vectors of ALL batches in global batch order, identical on every rank."""
+    Returns the vectors of ALL batches in global batch order, identical on every rank.
+    `shape` = (L, ld) when the caller knows it: ranks that own no batch then need no shape exchange, and nothing here
+    makes the host wait for the device (the exchange reads a device scalar back)."""
     import torch.distributed as dist
     rank, ws = world(group)
     if ws == 1 and not (FORCE_COLLECTIVES and _initialised()):
@@ -46,10 +49,13 @@ def gather_batch_vectors(local: Sequence[Tuple[int, torch.Tensor]], n_batches_to
         return []
     slots = (n_batches_total + ws - 1) // ws
     proto = local[0][1] if local else None
-    shape = torch.tensor(list(proto.shape) if proto is not None else [0, 0], dtype=torch.int64,
-                         device=proto.device if proto is not None else _default_device(group))
-    dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=group)          # ranks without a batch learn the shape
-    L, ld = int(shape[0]), int(shape[1])
+    if shape is not None:
+        L, ld = int(shape[0]), int(shape[1])
+    else:
+        sh = torch.tensor(list(proto.shape) if proto is not None else [0, 0], dtype=torch.int64,
+                          device=proto.device if proto is not None else _default_device(group))
+        dist.all_reduce(sh, op=dist.ReduceOp.MAX, group=group)         # ranks without a batch learn the shape
+        L, ld = int(sh[0]), int(sh[1])
     dev = proto.device if proto is not None else _default_device(group)
     mine = torch.zeros(slots, L, ld, dtype=torch.float32, device=dev)
     for idx, v in local:
