@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     else                                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     TSTAMP(41);
     // ---- main loop: two wave groups in ping-pong.  A UNIT is half a K-tile: LOAD = 12 fragment reads
-    // (ds_read_b128), COMPUTE = 16 MFMAs with 4 LDS-DMA pieces issued BETWEEN the MFMAs (s_memtime stamps: a piece
+    // (ds_read_b128), COMPUTE = 16 MFMAs with 4 LDS-DMA pieces issued BETWEEN the MFMAs (behind pairs 0, 2, 4, 6; s_memtime stamps: a piece
     // costs ~140 cycles of issue in a burst of four, ~30 behind an MFMA), one s_barrier after each.  Waves 4-7 (the
     // SIMD partners of waves 0-3) run one barrier behind, so between any two barriers one wave of every SIMD feeds
     // the matrix pipe while its partner reads LDS:
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (half == 0 && kt < 6) TSTAMP(4 + 6 * kt);
-        // ---------------- COMPUTE (+ 4 DMA pieces behind MFMA pairs 1, 3, 5, 7)
+        // ---------------- COMPUTE (+ 4 DMA pieces behind MFMA pairs 0, 2, 4, 6)
         //   half 0: g0 carries B(kt+1) -> sb1, g1 carries A(kt+2) -> sa2
         //   half 1: g0 carries A(kt+2) -> sa2, g1 carries B(kt+2) -> sb (K-tile kt's slot: its reads ended a barrier ago)
         const bool take_a = (half == 0) == (wm != 0);
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             for (int b = 0; b < C::TN; ++b)     // operands swapped: D rows <-> n (weight rows), D columns <-> m
               acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s2][b], fa[s2][a], acc[a][b], 0, 0, 0)
                                : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][a], fb[s2][b], acc[a][b], 0, 0, 0);
-            const int pair = s2 * 4 + a;        // 8 MFMA pairs per unit
-            if (pair & 1) {
+            const int pair = s2 * 4 + a;        // 8 MFMA pairs per unit; a piece behind pairs 0, 2, 4, 6: the last one
+            if (!(pair & 1)) {                  // still has MFMAs behind it
               __builtin_amdgcn_sched_barrier(0);
               if (dma_on) {
                 if (take_a) GLDS_A(dbase + dsrc[pair >> 1], smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
