@@ -118,7 +118,8 @@ __device__ __forceinline__ f32x2 gelu_erf_pk(uint32_t pk, f32x2& pre) {
   return gelu_erf_core(pre, ax);
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  bf16x2 v; v[0] = (bf16)lo; v[1] = (bf16)hi;     // one v_cvt_pk_bf16_f32
+  f32x2 f; f.x = lo; f.y = hi;
+  const bf16x2 v = __builtin_convertvector(f, bf16x2);     // one v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf16lo_f32(uint32_t pk) { return __builtin_bit_cast(float, pk << 16); }

@@ -23,6 +23,7 @@
 // and leaves as whole 128-byte row segments.  No VGPR ever waits for an x load.
 #pragma once
 #include "gemm.hip.h"
+#include <type_traits>
 #ifndef STAMP
 #define STAMP(slot) do {} while (0)
 #endif
@@ -178,11 +179,13 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       if (nk > 1) stage_b(C::B1, 1);                           // its B(1) pieces (B1 is free: the tile-start barrier)
       asm volatile("s_barrier" ::: "memory");                  // the skew
     }
-    for (int kt = 0; kt < nk; ++kt) {
+    // One K-tile.  B_ON / A_ON (is there a B(kt+1) / an A(kt+2) to fetch?) are compile-time: the steady state
+    // (kt < nk - 2) carries no conditional around its DMA pieces, the last two K-tiles are separate instances.
+    auto ktile = [&](int kt, auto b_on_c, auto a_on_c) {
+      constexpr bool b_on = decltype(b_on_c)::value, a_on = decltype(a_on_c)::value;
       const int sa1 = sa == C::A0 ? C::A1 : (sa == C::A1 ? C::A2 : C::A0);
       const int sa2 = sa1 == C::A0 ? C::A1 : (sa1 == C::A1 ? C::A2 : C::A0);
       const int sb1 = sb ^ (C::B0 ^ C::B1);
-      const bool b_on = kt + 1 < nk, a_on = kt + 2 < nk;       // workgroup-uniform
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         // ---------------- LOAD
@@ -248,6 +251,12 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
       }
       sa = sa1; sb = sb1;
+    };
+    {
+      int kt = 0;
+      for (; kt + 2 < nk; ++kt) ktile(kt, std::true_type{}, std::true_type{});
+      if (kt + 1 < nk) { ktile(kt, std::true_type{}, std::false_type{}); ++kt; }
+      if (kt < nk) ktile(kt, std::false_type{}, std::false_type{});
     }
     TSTAMP(60);
 
