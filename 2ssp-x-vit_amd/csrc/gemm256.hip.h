@@ -40,6 +40,13 @@
 // Measured (gemm_bench + rocprofv3 PMC, 63040-row shapes, interleaved runs): with NT loads QKV's HBM-side fetch halves
 // (182 -> 99 MB per launch, L2 hit rate 72 -> 79 %) and yet every shape runs 5-9 % SLOWER; NT stores alone are within
 // noise of the default.  The default policy stays; the switch is kept for A/B runs only.
+// LDS-DMA pieces (of 4 per unit) issued in the LOAD phase instead of between the MFMAs.  Measured on the 63040-row
+// shapes (interleaved runs): 1 -> 1-2 % slower, 2 -> 3 % slower, 4 (a burst, ~140 cycles per piece) -> 25 % slower than
+// 0, although the loading wave then idles ~400 cycles per phase at the barrier: a piece issued beside the partner's
+// MFMAs slows those down by more than it saves.  Kept as a switch for A/B runs.
+#ifndef PP_NL
+#define PP_NL 0
+#endif
 #ifndef GEMM_NT
 #define GEMM_NT 0
 #endif
@@ -188,6 +195,22 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       const int sb1 = sb ^ (C::B0 ^ C::B1);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
+        //   half 0: g0 carries B(kt+1) -> sb1, g1 carries A(kt+2) -> sa2
+        //   half 1: g0 carries A(kt+2) -> sa2, g1 carries B(kt+2) -> sb (K-tile kt's slot: its reads end with this LOAD)
+        const bool take_a = (half == 0) == (wm != 0);
+        const bool dma_on = (half == 0 && !wm) ? b_on : a_on;
+        const char* const dbase = (half == 0 ? ride_base0 : ride_base1)                      // wave-uniform: SGPRs
+                                  + (size_t)(((half == 0 && !wm) ? kt + 1 : kt + 2) * (GEMM_BK * 2));
+        const int dlds = take_a ? sa2 : (half == 0 ? sb1 : sb);
+        const uint32_t (&dsrc)[4] = half == 0 ? ride0 : ride1;
+        // PP_NL of the unit's 4 pieces go out in its LOAD phase (behind the fragment reads, in the time the wave would
+        // otherwise wait at the barrier), the rest between the MFMAs — except for g1's half 1, whose target slot is
+        // still being read during that LOAD
+        const bool early_ok = !(half == 1 && wm);
+        auto piece = [&](int i) {
+          if (take_a) GLDS_A(dbase + dsrc[i], smem + dlds + (wave + 8 * i) * 1024);
+          else        glds16(dbase + dsrc[i], smem + dlds + (wave + 8 * i) * 1024);
+        };
         // ---------------- LOAD
         if (half == 0 && kt < 6) TSTAMP(1 + 6 * kt);
         {
@@ -202,6 +225,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             for (int i = 0; i < C::TM; ++i) fa[s2][i] = *(const bf16x8*)(As + o + i * 4096);
           }
         }
+        if (PP_NL > 0 && dma_on && early_ok) {
+#pragma unroll
+          for (int i = 0; i < PP_NL; ++i) piece(i);
+        }
         if (half == 0 && kt < 6) TSTAMP(2 + 6 * kt);
         if (half == 1 && wm) {      // g1: end of phase 4kt+3
           if (a_on) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -214,15 +241,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (half == 0 && kt < 6) TSTAMP(4 + 6 * kt);
-        // ---------------- COMPUTE (+ 4 DMA pieces behind MFMA pairs 0, 2, 4, 6)
-        //   half 0: g0 carries B(kt+1) -> sb1, g1 carries A(kt+2) -> sa2
-        //   half 1: g0 carries A(kt+2) -> sa2, g1 carries B(kt+2) -> sb (K-tile kt's slot: its reads ended a barrier ago)
-        const bool take_a = (half == 0) == (wm != 0);
-        const bool dma_on = (half == 0 && !wm) ? b_on : a_on;
-        const char* const dbase = (half == 0 ? ride_base0 : ride_base1)                      // wave-uniform: SGPRs
-                                  + (size_t)(((half == 0 && !wm) ? kt + 1 : kt + 2) * (GEMM_BK * 2));
-        const int dlds = take_a ? sa2 : (half == 0 ? sb1 : sb);
-        const uint32_t (&dsrc)[4] = half == 0 ? ride0 : ride1;
+        // ---------------- COMPUTE (+ the remaining DMA pieces behind MFMA pairs 0, 2, 4, 6)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -234,10 +253,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             const int pair = s2 * 4 + a;        // 8 MFMA pairs per unit; a piece behind pairs 0, 2, 4, 6: the last one
             if (!(pair & 1)) {                  // still has MFMAs behind it
               __builtin_amdgcn_sched_barrier(0);
-              if (dma_on) {
-                if (take_a) GLDS_A(dbase + dsrc[pair >> 1], smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
-                else        glds16(dbase + dsrc[pair >> 1], smem + dlds + (wave + 8 * (pair >> 1)) * 1024);
-              }
+              if (dma_on && !(PP_NL > 0 && early_ok && (pair >> 1) < PP_NL)) piece(pair >> 1);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
