@@ -575,3 +575,51 @@ def test_persistent_gemm_edge_shapes_bitwise_vs_small_tile_kernel(gpu):
         out = subprocess.run([exe] + shape.split() + ["2"], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "bit-identical" in out.stdout and "FAIL" not in out.stdout, f"{shape}: {out.stdout}"
+
+
+def test_full_size_vit_b16_properties(gpu):
+    """BASELINE configs[1] at its real size (ViT-B/16, 1000 classes, 512 calibration images in batches of 64, the
+    oracle would take minutes): size-independent properties instead of an element-wise oracle comparison.
+      * packing invariance: one batch per launch == eight batches per launch, bit for bit (slab layout, both GEMM kernels)
+      * additivity: the score vector of the whole set == mean of the per-batch sums, formed in batch order
+      * run-to-run determinism of scores, masks and search counts
+      * prefix-cached depth search == a full re-run per candidate (integers), 128 evaluation images
+      * every score finite and positive; masks prune exactly t neurons per block"""
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_base_patch16_224", classes=1000, seed=0, std=0.02, eps=1e-6, spread=4.0)
+    eng = VitEngine(w, max_images=512)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    calib = [{"pixel_values": torch.randn(64, 3, 224, 224, generator=g, device="cuda")} for _ in range(8)]
+    d_ints = [3072] * 12
+    one = core.stage1_scores(eng, calib, d_ints, "pre_gelu", chunk_images=64)
+    packed = core.stage1_scores(eng, calib, d_ints, "pre_gelu", chunk_images=512)
+    again = core.stage1_scores(eng, calib, d_ints, "pre_gelu", chunk_images=512)
+    for a, b, c in zip(one, packed, again):
+        assert torch.equal(a, b) and torch.equal(b, c)
+        assert bool(torch.isfinite(a).all()) and float(a.min()) > 0
+    # additivity: per-batch un-normalised sums, added in batch order, divided by the sample count
+    total = None
+    for b in calib:
+        part = core.stage1_scores(eng, [b], d_ints, "pre_gelu", chunk_images=64)
+        vec = torch.stack([p * 64 for p in part])                      # back to the batch's sum (exact: power of two)
+        total = vec if total is None else total + vec
+    for l in range(12):
+        assert torch.equal(total[l] / 512, packed[l])
+    t = 1120
+    for imp in packed:
+        keep, _ = torch.sort(torch.argsort(imp, descending=True)[: imp.numel() - t])
+        m = torch.ones(imp.numel(), dtype=torch.int16); m[keep] = 0
+        assert int(m.sum()) == t
+    # stage 2 on 128 images with teacher labels
+    evalb = []
+    for _ in range(2):
+        px = torch.randn(64, 3, 224, 224, generator=g, device="cuda")
+        x = eng.embed(px); eng.layers(x, 64)
+        evalb.append({"pixel_values": px, "labels": eng.head(x, 64, want_pred=True)[1].long()})
+    base, cand, n = core.depth_search_counts(eng, evalb, 12, batch_limit=None, chunk_images=128)
+    assert n == 128 and base == 128                                    # teacher labels: the dense model is 100 % right
+    assert (base, cand, n) == core.depth_search_counts(eng, evalb, 12, batch_limit=None, chunk_images=64)
+    for c in (0, 5, 11):
+        assert core.top1_counts(eng, evalb, attn_skip=[c], chunk_images=128) == (cand[c], 128)
