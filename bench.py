@@ -234,6 +234,25 @@ def main():
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
                                 "flops_per_launch_avg": prof.flops / prof.launches,
                                 "shapes": f"[{eng.rows(min(args.calib, args.calib_chunk or args.batch), args.batch)} | {(args.eval_chunk or n_eval) * tokens} | {n_eval}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk | CLS tail)"}
+        if not args.no_roofline:
+            # the HBM-bound kernel of the path on its own: the standalone activation-L2 accumulate (a2) over one
+            # layer's activation of one calibration batch, outside the timed region (in the step it is fused into the
+            # fc1 epilogue and reads nothing from HBM).  Algorithmic bytes = n*N*d_int*2 read once.
+            act = torch.randn(args.batch, tokens, d_int, device=dev, dtype=torch.float32).to(torch.bfloat16)
+            for _ in range(3):
+                eng.act_l2_accum(act)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                eng.act_l2_accum(act)
+            e1.record(); e1.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            gbps = act.numel() * 2 / (us * 1e-6) / 1e9
+            line["act_l2_kernel"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
+                                     "frac": round(gbps / 8000.0, 4), "bytes_per_launch": act.numel() * 2,
+                                     "avg_launch_us": round(us, 2),
+                                     "kernel": "act_l2_norms_kernel<bf16> + score_colsum_kernel (standalone a2; 2 launches per call)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, weights)
         print(json.dumps(line), flush=True)
