@@ -4,6 +4,7 @@ reference-named wrappers in `vit_pruning` (live nn.Module in, like the reference
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
@@ -239,7 +240,8 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
 @torch.no_grad()
 def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional[int] = 5, process_group=None,
                         removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None,
-                        chunk_images: Optional[int] = None, defer: bool = False):
+                        chunk_images: Optional[int] = None, defer: bool = False, aux_engine=None, aux_stream=None,
+                        aux_lead: float = 0.0):
     """One pass over the eval batches that yields the baseline AND every candidate's correct-count.
 
     The reference deep-copies the model and re-runs the whole forward per candidate (mask_conjunction.py:339-355,
@@ -248,7 +250,13 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
     0..i-1 are bit-identical to the baseline, so the result equals a full re-run while executing
     L(L+1)/2 + L block passes per batch instead of L(L+1).
     Returns (baseline_correct, [candidate_correct per block], total); with `defer=True` a zero-argument callable
-    that waits for the device and returns that tuple."""
+    that waits for the device and returns that tuple.
+
+    `aux_engine` + `aux_stream`: a second engine (same weights, own workspace) on a second HIP stream takes a share
+    of the candidates once the baseline has produced their snapshots — candidates are independent, and two streams
+    let the memory-bound kernels of one (LayerNorm, epilogue tails) run beside the matrix-bound kernels of the other.
+    `aux_lead` = work already queued on that stream, in block passes of this chunk size (bench: the stage-1 launch);
+    the split balances (baseline + main candidates) against (lead + aux candidates).  Integer counts: same result."""
     rank, ws = _dist.world(process_group)
     L = depth
     counts_dev = None
@@ -268,13 +276,31 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
             eng.layers(x, n, l, l + 1, removed)
         # x now enters the last block: every pass finishes with the CLS-only tail, which leaves x untouched
         eng.tail(x, n, removed, labels=labels, correct=counts_dev[L:L + 1])
+        on_aux = set()
+        if aux_engine is not None and aux_stream is not None and n <= aux_engine.max_images:
+            load_main, load_aux = float(L - 1), float(aux_lead)          # greedy split, longest candidates first
+            for c in sorted(cands):
+                cost = float(L - 1 - c) + 0.2
+                if load_aux + cost < load_main:
+                    on_aux.add(c); load_aux += cost
+                else:
+                    load_main += cost
+            main = torch.cuda.current_stream(eng.device)
+            aux_stream.wait_stream(main)                                   # snapshots and labels are ready
         for c in cands:
-            if c == L - 1:
-                eng.tail(x, n, removed + [c], labels=labels, correct=counts_dev[c:c + 1])
-                continue
-            xc = cache.pop(c)
-            eng.layers(xc, n, c, L - 1, removed + [c])
-            eng.tail(xc, n, removed + [c], labels=labels, correct=counts_dev[c:c + 1])
+            e, ctx = (aux_engine, torch.cuda.stream(aux_stream)) if c in on_aux else (eng, contextlib.nullcontext())
+            with ctx:
+                if c == L - 1:
+                    e.tail(x, n, removed + [c], labels=labels, correct=counts_dev[c:c + 1])
+                    continue
+                xc = cache.pop(c)
+                if c in on_aux:
+                    xc.record_stream(aux_stream)
+                e.layers(xc, n, c, L - 1, removed + [c])
+                e.tail(xc, n, removed + [c], labels=labels, correct=counts_dev[c:c + 1])
+        if on_aux:
+            x.record_stream(aux_stream); labels.record_stream(aux_stream)
+            torch.cuda.current_stream(eng.device).wait_stream(aux_stream)
         total += n
     if counts_dev is None:
         counts = torch.zeros(L + 2, dtype=torch.int64)

@@ -623,3 +623,10 @@ def test_full_size_vit_b16_properties(gpu):
     assert (base, cand, n) == core.depth_search_counts(eng, evalb, 12, batch_limit=None, chunk_images=64)
     for c in (0, 5, 11):
         assert core.top1_counts(eng, evalb, attn_skip=[c], chunk_images=128) == (cand[c], 128)
+    # a second engine on a second stream takes a share of the candidates: same integers
+    eng2 = VitEngine(w, max_images=128)
+    side = torch.cuda.Stream()
+    assert (base, cand, n) == core.depth_search_counts(eng, evalb, 12, batch_limit=None, chunk_images=128,
+                                                       aux_engine=eng2, aux_stream=side, aux_lead=10.0)
+    assert (base, cand, n) == core.depth_search_counts(eng, evalb, 12, batch_limit=None, chunk_images=64,
+                                                       aux_engine=eng2, aux_stream=side)
