@@ -5,22 +5,25 @@
 //
 // LDS (all 160 KiB, one array):   A0 | A1 | B0 | B1 | A2     32 KiB each
 //   main loop   asymmetric ring as in gemm.hip.h: the A panel (streams from HBM / Infinity Cache) is three K-tiles
-//               deep, the weight panel (L2-resident) two.  Per K-tile a wave issues [B(kt+1) x4, A(kt+2) x4] by
-//               16-byte LDS-DMA and the K-tile boundary is ONE counted `s_waitcnt vmcnt(4)` + raw s_barrier, so
-//               A(kt+2) stays in flight across the barrier (the two-slot ring of round 1 waited ~420 cycles per
-//               K-tile for a drain to vmcnt(0)).
-//   tile change right after the last K-tile's barrier the NEXT tile's B(0), A(0), A(1) go out into B0, A0, A1; the
-//               epilogue then runs out of B1 | A2 (64 KiB = 8 KiB per wave, wave-private, no barrier inside).
-//               vmcnt counts loads, stores and LDS-DMA together in issue order, so the next main loop starts behind
-//               a counted wait that leaves only the epilogue's LAST stores in flight — nothing is ever drained to
-//               zero between two main loops (full tiles; an edge tile takes the conservative vmcnt(0) path).
+//               deep, the weight panel (L2-resident) two, filled by 16-byte LDS-DMA (1-KiB pieces, 8 per wave per
+//               K-tile).  The two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) run in PING-PONG,
+//               half a K-tile per step: one group reads its 12 fragments from LDS while the other issues 16 MFMAs
+//               with its 4 DMA pieces between them (see the phase table at the loop); 4 raw s_barriers and ONE
+//               counted `s_waitcnt vmcnt(4)` per K-tile, so A(kt+2) stays in flight across the K-tile boundary.
+//               The steady-state K-tile body is a separate compile-time instance without any conditional.
+//   tile change right after the last K-tile the NEXT tile's B(0), A(0), A(1) go out into B0, A0, A1; the epilogue
+//               then runs out of B1 | A2 (64 KiB = 8 KiB per wave, wave-private, no barrier inside).  vmcnt counts
+//               loads, stores and LDS-DMA together in issue order, so the next main loop starts behind a counted
+//               wait that leaves only the epilogue's LAST stores in flight — nothing is ever drained to zero between
+//               two main loops (full tiles; an edge tile takes the conservative vmcnt(0) path).
 //
-// Epilogue: the MFMA operands are swapped (acc = W_frag x A_frag), so a lane owns ONE output row and FOUR
+// Epilogues: the MFMA operands are swapped (acc = W_frag x A_frag), so a lane owns ONE output row and FOUR
 // consecutive columns per register quad.  Against the row-of-4-rows layout of the plain order this makes the bias
-// add and the bf16 conversion packed, replaces 16 two-byte LDS stores per 32x32 block by 4 eight-byte ones, and —
-// for the residual epilogue — lets the fp32 x tile ride the LDS-DMA engine: x is DMAed into the wave's staging
-// buffer (double-buffered 32x32 blocks, swizzled on the source address), updated in place from the accumulators,
-// and leaves as whole 128-byte row segments.  No VGPR ever waits for an x load.
+// add and the bf16 conversion packed and replaces 16 two-byte LDS stores per 32x32 block by 4 eight-byte ones;
+// outputs leave through a wave-private LDS tile as whole 128-byte row segments.  The residual epilogue keeps 16
+// coalesced loads of the fp32 x tile in flight per wave (raw-buffer addressing: no 64-bit address registers) and
+// adds the accumulators to them in that row-contiguous layout.  The stage-1 scoring variant keeps the plain operand
+// order (see the template comment).
 #pragma once
 #include "gemm.hip.h"
 #include <type_traits>
