@@ -241,7 +241,7 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
 def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional[int] = 5, process_group=None,
                         removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None,
                         chunk_images: Optional[int] = None, defer: bool = False, aux_engine=None, aux_stream=None,
-                        aux_lead: float = 0.0):
+                        aux_lead: float = 0.0, batch_candidates: bool = False):
     """One pass over the eval batches that yields the baseline AND every candidate's correct-count.
 
     The reference deep-copies the model and re-runs the whole forward per candidate (mask_conjunction.py:339-355,
@@ -269,6 +269,27 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
             counts_dev = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
         n = int(px.size(0))
         x = eng.embed(px)
+        if (batch_candidates and not removed and cands == list(range(L)) and aux_engine is None
+                and eng.max_images >= (L - 1) * n):
+            # Layer-major search: the snapshots sit side by side in one buffer, and at block l every candidate that
+            # is already under way (c < l) runs the block in ONE launch of l*n images — same per-candidate arithmetic
+            # in the same order, l + 1 launches per block become 2, and the persistent GEMMs lose their partial last
+            # round (k*246.25 row panels instead of 246.25).  Candidate l itself runs block l alone (its attention is
+            # bypassed).  Needs an engine workspace for (L-1)*n images.
+            rows = x.shape[0]
+            xb = torch.empty((L - 1) * rows, x.shape[1], dtype=x.dtype, device=x.device)
+            for l in range(L - 1):
+                xb[l * rows:(l + 1) * rows].copy_(x)                       # snapshot l = input of block l
+                eng.layers(x, n, l, l + 1)                                 # baseline
+                eng.layers(xb[l * rows:(l + 1) * rows], n, l, l + 1, [l])  # candidate l: block l without attention
+                if l:
+                    eng.layers(xb[:l * rows], l * n, l, l + 1)             # candidates 0..l-1: block l as is
+            eng.tail(x, n, None, labels=labels, correct=counts_dev[L:L + 1])
+            for c in range(L - 1):
+                eng.tail(xb[c * rows:(c + 1) * rows], n, None, labels=labels, correct=counts_dev[c:c + 1])
+            eng.tail(x, n, [L - 1], labels=labels, correct=counts_dev[L - 1:L])
+            total += n
+            continue
         cache = {}
         for l in range(L - 1):
             if l in cands:

@@ -110,6 +110,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-batch-candidates", action="store_true",
+                    help="candidate-major search (one launch per candidate and block) instead of the layer-major one, "
+                         "in which all candidates under way run a block in ONE launch (engine workspace for "
+                         "(depth-1) x eval images)")
     ap.add_argument("--two-streams", action="store_true",
                     help="run stage 1 and a share of the search candidates on a second HIP stream with its own engine "
                          "workspace (5 %% faster end to end; per-launch durations then include the share of the "
@@ -140,7 +144,11 @@ def main():
     img, patch, dim, heads, d_int, depth = VIT_CONFIGS[args.model]
     tokens = (img // patch) ** 2 + 1
     weights = synthetic_weights(args.model, classes=1000, seed=0, std=0.02, eps=1e-6, spread=4.0)
-    eng = VitEngine(weights, device=dev, max_images=max(args.batch, args.eval_batches * args.batch, args.calib_chunk))
+    cap = max(args.batch, args.eval_batches * args.batch, args.calib_chunk)
+    args.batch_candidates = not args.no_batch_candidates and not args.two_streams
+    if args.batch_candidates:
+        cap = max(cap, (depth - 1) * (args.eval_chunk or args.eval_batches * args.batch))
+    eng = VitEngine(weights, device=dev, max_images=cap)
     # --two-streams: stage 1 (calibration scores) and stage 2 (depth search on the dense model) are independent, and so
     # are the search candidates: with a second engine workspace (weights uploaded twice, 173 MB) on a second HIP stream
     # the memory-bound kernels of one stream (LayerNorm, attention, epilogue tails) overlap the matrix-bound kernels of
@@ -179,7 +187,8 @@ def main():
         search = core.depth_search_counts(eng, eval_loader, depth, batch_limit=None, process_group=pg,
                                           chunk_images=args.eval_chunk or n_eval, defer=True,
                                           aux_engine=None if side is None else eng1, aux_stream=side,
-                                          aux_lead=args.calib * depth / max(1, args.eval_chunk or n_eval))
+                                          aux_lead=args.calib * depth / max(1, args.eval_chunk or n_eval),
+                                          batch_candidates=args.batch_candidates and side is None)
         imps = scores()
         masks = []
         t = plan.per_block_neurons_to_prune
@@ -245,18 +254,19 @@ def main():
             "calib_images_per_sec": round(world * args.calib / s1_s, 1),
             "executed_block_pass_fraction": round(executed / reference_equiv, 4),
             "selected_blocks": out[3], "pruned_neurons_per_block": plan.per_block_neurons_to_prune,
-            "streams": 2 if args.two_streams else 1,
+            "streams": 2 if args.two_streams else 1, "search": "layer-major" if args.batch_candidates else "candidate-major",
         }
         if prof is not None and prof.launches:
             # dominant kernel family: fc1 (+bias +erf-GELU; + fused activation-L2 partials in stage 1).
             # achieved = algorithmic flops (2*M*N*K summed over the recorded launches) / summed HIP-event durations.
             ach = prof.flops / (prof.total_ms * 1e-3) / 1e12
+            lm = f", x 1..{depth - 2} in the layer-major search" if args.batch_candidates else ""
             line["roofline"] = {"bound": "mfma", "kernel": "fc1 GEMM family: gemm256_bf16_kernel<EPI_FC1,SCORE> persistent 256x256 (stage 1: + fused activation-L2 partials; search passes: SCORE=0) and gemm_bf16_kernel<EPI_FC1> 128x128 (CLS tail); bias + erf-GELU fused",
                                 "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
                                 "flops_per_launch_avg": prof.flops / prof.launches,
-                                "shapes": f"[{eng.rows(min(args.calib, args.calib_chunk or args.batch), args.batch)} | {(args.eval_chunk or n_eval) * tokens} | {n_eval}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk | CLS tail)"}
+                                "shapes": f"[{eng.rows(min(args.calib, args.calib_chunk or args.batch), args.batch)} | {(args.eval_chunk or n_eval) * tokens} | {n_eval}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk{lm} | CLS tail)"}
         if not args.no_roofline:
             # the HBM-bound kernel of the path on its own: the standalone activation-L2 accumulate (a2) over one
             # layer's activation of one calibration batch, outside the timed region (in the step it is fused into the

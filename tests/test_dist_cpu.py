@@ -181,3 +181,15 @@ def test_deferred_results_equal_immediate_ones():
     assert core.depth_search_counts(eng, batches, eng.depth, batch_limit=None, defer=True)() == \
         core.depth_search_counts(eng, batches, eng.depth, batch_limit=None)
     assert [float(t.sum()) for t in core.stage1_scores(eng, [], d_ints, "pre_gelu", defer=True)()] == [0.0] * len(d_ints)
+
+
+def test_layer_major_batched_search_gives_the_same_counts():
+    """batch_candidates=True runs every block once for all candidates already under way (one launch of l*n images);
+    per candidate the arithmetic and its order are unchanged, so the integers are."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import core
+    w, batches = _batches()
+    eng = OracleBackedEngine(build_from_flat(w, "timm"), max_images=1000)
+    ref = core.depth_search_counts(eng, batches, eng.depth, batch_limit=None, chunk_images=64)
+    assert core.depth_search_counts(eng, batches, eng.depth, batch_limit=None, chunk_images=64, batch_candidates=True) == ref
+    assert core.depth_search_counts(eng, batches, eng.depth, batch_limit=None, chunk_images=7, batch_candidates=True) == ref
