@@ -270,24 +270,24 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
         n = int(px.size(0))
         x = eng.embed(px)
         if (batch_candidates and not removed and cands == list(range(L)) and aux_engine is None
-                and eng.max_images >= (L - 1) * n):
-            # Layer-major search: the snapshots sit side by side in one buffer, and at block l every candidate that
-            # is already under way (c < l) runs the block in ONE launch of l*n images — same per-candidate arithmetic
-            # in the same order, l + 1 launches per block become 2, and the persistent GEMMs lose their partial last
-            # round (k*246.25 row panels instead of 246.25).  Candidate l itself runs block l alone (its attention is
-            # bypassed).  Needs an engine workspace for (L-1)*n images.
+                and eng.max_images >= L * n):
+            # Layer-major search: the baseline (slot 0) and the snapshots (candidate c in slot c + 1) sit side by side
+            # in one buffer, and at block l the baseline and every candidate already under way (c < l) run the block
+            # in ONE launch of (l + 1)*n images — same per-image arithmetic in the same order, l + 2 launches per block
+            # become 2, and the persistent GEMMs lose their partial last round ((l+1)*246.25 row panels instead of
+            # 246.25).  Candidate l itself runs block l alone (its attention is bypassed).  Needs an engine workspace
+            # for L*n images.
             rows = x.shape[0]
-            xb = torch.empty((L - 1) * rows, x.shape[1], dtype=x.dtype, device=x.device)
+            xb = torch.empty(L * rows, x.shape[1], dtype=x.dtype, device=x.device)
+            xb[:rows].copy_(x)
             for l in range(L - 1):
-                xb[l * rows:(l + 1) * rows].copy_(x)                       # snapshot l = input of block l
-                eng.layers(x, n, l, l + 1)                                 # baseline
-                eng.layers(xb[l * rows:(l + 1) * rows], n, l, l + 1, [l])  # candidate l: block l without attention
-                if l:
-                    eng.layers(xb[:l * rows], l * n, l, l + 1)             # candidates 0..l-1: block l as is
-            eng.tail(x, n, None, labels=labels, correct=counts_dev[L:L + 1])
+                xb[(l + 1) * rows:(l + 2) * rows].copy_(xb[:rows])                 # snapshot: input of block l
+                eng.layers(xb[:(l + 1) * rows], (l + 1) * n, l, l + 1)             # baseline + candidates 0..l-1
+                eng.layers(xb[(l + 1) * rows:(l + 2) * rows], n, l, l + 1, [l])    # candidate l: no attention in block l
+            eng.tail(xb[:rows], n, None, labels=labels, correct=counts_dev[L:L + 1])
             for c in range(L - 1):
-                eng.tail(xb[c * rows:(c + 1) * rows], n, None, labels=labels, correct=counts_dev[c:c + 1])
-            eng.tail(x, n, [L - 1], labels=labels, correct=counts_dev[L - 1:L])
+                eng.tail(xb[(c + 1) * rows:(c + 2) * rows], n, None, labels=labels, correct=counts_dev[c:c + 1])
+            eng.tail(xb[:rows], n, [L - 1], labels=labels, correct=counts_dev[L - 1:L])
             total += n
             continue
         cache = {}

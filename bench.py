@@ -147,7 +147,7 @@ def main():
     cap = max(args.batch, args.eval_batches * args.batch, args.calib_chunk)
     args.batch_candidates = not args.no_batch_candidates and not args.two_streams
     if args.batch_candidates:
-        cap = max(cap, (depth - 1) * (args.eval_chunk or args.eval_batches * args.batch))
+        cap = max(cap, depth * (args.eval_chunk or args.eval_batches * args.batch))
     eng = VitEngine(weights, device=dev, max_images=cap)
     # --two-streams: stage 1 (calibration scores) and stage 2 (depth search on the dense model) are independent, and so
     # are the search candidates: with a second engine workspace (weights uploaded twice, 173 MB) on a second HIP stream
@@ -260,7 +260,7 @@ def main():
             # dominant kernel family: fc1 (+bias +erf-GELU; + fused activation-L2 partials in stage 1).
             # achieved = algorithmic flops (2*M*N*K summed over the recorded launches) / summed HIP-event durations.
             ach = prof.flops / (prof.total_ms * 1e-3) / 1e12
-            lm = f", x 1..{depth - 2} in the layer-major search" if args.batch_candidates else ""
+            lm = f", x 1..{depth - 1} in the layer-major search" if args.batch_candidates else ""
             line["roofline"] = {"bound": "mfma", "kernel": "fc1 GEMM family: gemm256_bf16_kernel<EPI_FC1,SCORE> persistent 256x256 (stage 1: + fused activation-L2 partials; search passes: SCORE=0) and gemm_bf16_kernel<EPI_FC1> 128x128 (CLS tail); bias + erf-GELU fused",
                                 "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),

@@ -624,7 +624,7 @@ def test_full_size_vit_b16_properties(gpu):
     for c in (0, 5, 11):
         assert core.top1_counts(eng, evalb, attn_skip=[c], chunk_images=128) == (cand[c], 128)
     # layer-major order (all candidates under way run a block in one launch of l*n images): same integers
-    eng3 = VitEngine(w, max_images=11 * 64)
+    eng3 = VitEngine(w, max_images=12 * 64)
     assert (base, cand, n) == core.depth_search_counts(eng3, evalb, 12, batch_limit=None, chunk_images=64,
                                                        batch_candidates=True)
     eng3.close()
