@@ -112,8 +112,12 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   // piece between two MFMAs costs no vector instruction besides itself
   uint32_t a_src[4], w_src[4];
   // what a wave carries in the first / second half of a K-tile (see the main loop): g0 B then A, g1 A then B
-  const char* const ride_base0 = (const char*)(wm ? g.A : g.W);
-  const char* const ride_base1 = (const char*)(wm ? g.W : g.A);
+  // All per-lane offsets are relative to the TILE's operand panels (64-bit wave-uniform bases, set per tile): a launch
+  // may span more than 4 GiB of activations (the layer-major search runs up to depth x 320 images per launch).
+  const char* a_tile = (const char*)g.A;                // g.A + m0 * lda
+  const char* w_tile = (const char*)g.W;                // g.W + n0 * ldw
+  const char* ride_base0 = nullptr;                     // half 0: g0 carries the weight panel, g1 the activation panel
+  const char* ride_base1 = nullptr;
   int m0 = 0, n0 = 0;
   float bias_next = 0.f;                                // bias[n0 + wn*64 + lane] of the tile being prefetched
   auto set_tile = [&](int tile) {
@@ -124,12 +128,14 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       const int row = (wave + 8 * i) * 8 + (lane >> 3);
       const int c_src = (lane & 7) ^ ((row >> 1) & 7);
       int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
-      a_src[i] = ((uint32_t)gr * (uint32_t)g.lda + c_src * 8) * 2;
-      w_src[i] = ((uint32_t)(n0 + row) * (uint32_t)g.ldw + c_src * 8) * 2;
+      a_src[i] = ((uint32_t)(gr - m0) * (uint32_t)g.lda + c_src * 8) * 2;
+      w_src[i] = ((uint32_t)row * (uint32_t)g.ldw + c_src * 8) * 2;
     }
+    a_tile = (const char*)(g.A + (size_t)m0 * g.lda);
+    w_tile = (const char*)(g.W + (size_t)n0 * g.ldw);
   };
-  auto piece_a = [&](int off, int kt, int i) { GLDS_A((const char*)g.A + (size_t)kt * (GEMM_BK * 2) + a_src[i], smem + off + (wave + 8 * i) * 1024); };
-  auto piece_b = [&](int off, int kt, int i) { glds16((const char*)g.W + (size_t)kt * (GEMM_BK * 2) + w_src[i], smem + off + (wave + 8 * i) * 1024); };
+  auto piece_a = [&](int off, int kt, int i) { GLDS_A(a_tile + (size_t)kt * (GEMM_BK * 2) + a_src[i], smem + off + (wave + 8 * i) * 1024); };
+  auto piece_b = [&](int off, int kt, int i) { glds16(w_tile + (size_t)kt * (GEMM_BK * 2) + w_src[i], smem + off + (wave + 8 * i) * 1024); };
   auto stage_a = [&](int off, int kt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_a(off, kt, i);
@@ -185,6 +191,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     uint32_t ride0[4], ride1[4];                               // the pieces carried in half 0 / half 1 (selected once per tile)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ride0[i] = wm ? a_src[i] : w_src[i]; ride1[i] = wm ? w_src[i] : a_src[i]; }
+    ride_base0 = wm ? a_tile : w_tile;
+    ride_base1 = wm ? w_tile : a_tile;
     if (wm) {                                                  // phase 0 of the tile: g1 has no unit to compute yet
       if (nk > 1) stage_b(C::B1, 1);                           // its B(1) pieces (B1 is free: the tile-start barrier)
       asm volatile("s_barrier" ::: "memory");                  // the skew
@@ -469,10 +477,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         // have here).  Rows past M get a per-lane offset beyond the buffer's range (the range check sees the VGPR
         // offset): their loads return 0 and their stores are dropped by the hardware — edge tiles take the same
         // straight-line code, no branches, no exec masks.
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(g.x, 0, 0x7ffffff0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xw, 0, 0x7ffffff0, 0x00020000);   // base = the wave's window
         const int lane_off = (dr * g.ldx + cc * 4) * 4;              // bytes: row dr of a piece, 16-byte chunk cc
         auto xoff = [&](int a, int b, int j) -> int {                // bytes, wave-uniform
-          return ((row0 + a * 32 + 8 * j) * g.ldx + col0 + b * 32) * 4;
+          return ((a * 32 + 8 * j) * g.ldx + b * 32) * 4;
         };
         const int rows_left = g.M - row0 - dr;                       // row a*32 + 8j + dr is valid iff a*32 + 8j < rows_left
         auto voff = [&](int a, int j) -> int { return (a * 32 + 8 * j < rows_left) ? lane_off : 0x7fffffff; };
