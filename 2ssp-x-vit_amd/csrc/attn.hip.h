@@ -13,6 +13,7 @@
 //
 // qkv layout: [n*tokens, 3*dim] bf16, columns [q | k | v][head][d_h] (timm's fused qkv == concat of HF q,k,v).
 #pragma once
+#include <type_traits>
 #include "common.hip.h"
 
 // CLS_ONLY (evaluation tail): only query 0 of every image is needed.  q then comes from a compact [n, dim] buffer
@@ -20,7 +21,7 @@
 // [n, dim] output.  The arithmetic for query 0 is the same instruction sequence as in the full kernel, so the tail
 // is bit-identical to running the whole block.
 template <int DH, int NT, bool CLS_ONLY = false>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, int ld, const bf16* __restrict__ qsrc,
+__global__ __launch_bounds__(256, (DH == 64 ? 2 : 1)) void attn_fwd_kernel(const bf16* __restrict__ qkv, int ld, const bf16* __restrict__ qsrc,
                                                       size_t q_img_stride, int q_ld, bf16* __restrict__ out,
                                                       size_t o_img_stride, int ldo, int tokens, int dim, float scale, RowMap rm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -51,7 +52,45 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const size_t img_row = (size_t)row_of(rm, img);
   const bf16* base = qkv + img_row * ld + head * DH;
 
-  // ---- stage K, V
+  // Q fragments of the wave's first query tile go out first; the next tile's are fetched behind the current tile's
+  // QK^T (software pipeline: no query load is ever waited for at the top of a tile)
+  const bf16* qbase = (CLS_ONLY ? qsrc + (size_t)img * q_img_stride : qsrc + img_row * ld) + head * DH;
+  auto load_q = [&](int qt, bf16x8 (&dst)[KS]) {
+    const int q = qt * 32 + l31;
+    const int qc = q < tokens ? q : tokens - 1;
+    const bf16* qp = qbase + (size_t)qc * q_ld + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) dst[s] = *(const bf16x8*)(qp + 16 * s);
+  };
+  // ---- stage K, V.  SPLIT (d_h = 64, full kernel): every wave issues Q, then its NT pieces of K, then its NT pieces
+  // of V, and waits with a COUNTED vmcnt(NT) — QK^T and the softmax run while V is still in flight; V is waited for
+  // (and the second barrier paid) in front of the first P V product.  The Q loads of this flow are inline asm with
+  // explicit waits tied to the registers: a compiler-tracked load would get a conservative vmcnt(0) in front of its
+  // first use, which would also wait for V.
+  constexpr bool SPLIT = DMA64 && !CLS_ONLY && NT >= 4;
+  auto load_q_asm = [&](int qt, bf16x8 (&dst)[KS]) {
+    const int q = qt * 32 + l31;
+    const int qc = q < tokens ? q : tokens - 1;
+    const bf16* qp = qbase + (size_t)qc * q_ld + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f32x4 t;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(t) : "v"(qp + 16 * s) : "memory");
+      dst[s] = __builtin_bit_cast(bf16x8, t);
+    }
+  };
+  auto wait_q = [&](bf16x8 (&dst)[KS], auto cnt) {    // s_waitcnt vmcnt(cnt) that the uses of dst[] cannot move above
+    static_assert(KS == 4 || !SPLIT, "wait_q ties four fragments");
+    f32x4 t0 = __builtin_bit_cast(f32x4, dst[0]), t1 = __builtin_bit_cast(f32x4, dst[1]);
+    f32x4 t2 = __builtin_bit_cast(f32x4, dst[KS > 2 ? 2 : 0]), t3 = __builtin_bit_cast(f32x4, dst[KS > 3 ? 3 : 0]);
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "n"(decltype(cnt)::value) : "memory");
+    dst[0] = __builtin_bit_cast(bf16x8, t0); dst[1] = __builtin_bit_cast(bf16x8, t1);
+    if (KS > 2) dst[2] = __builtin_bit_cast(bf16x8, t2);
+    if (KS > 3) dst[3] = __builtin_bit_cast(bf16x8, t3);
+  };
+  bf16x8 qnext[KS];
+  if constexpr (SPLIT) load_q_asm(wave, qnext);
+  else if (wave < (CLS_ONLY ? 1 : NT)) load_q(wave, qnext);
   if constexpr (DMA80) {
     for (int piece = wave; piece < NKEY * CH / 64; piece += 4) {
       const int gch = piece * 64 + lane, row = gch / CH, c = gch - row * CH;
@@ -62,6 +101,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     }
   } else if constexpr (DMA64) {
     // rows past `tokens` copy the last valid row: finite values, masked out of the softmax (p = 0) below
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int piece = wave + 4 * i, row = piece * 8 + (lane >> 3), c = lane & 7;
+        const int rc = row < tokens ? row : tokens - 1;
+        glds16(base + (size_t)rc * ld + dim + ((c ^ ((row >> 1) & 7)) << 3), Ks + piece * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int piece = wave + 4 * i, row = piece * 8 + (lane >> 3), c = lane & 7;
+        const int rc = row < tokens ? row : tokens - 1;
+        glds16(base + (size_t)rc * ld + 2 * dim + ((c ^ (((row >> 1) & 1) << 2)) << 3), Vs + piece * 1024);
+      }
+    } else
     for (int piece = wave; piece < NKEY / 8; piece += 4) {
       const int row = piece * 8 + (lane >> 3), c = lane & 7;
       const int rc = row < tokens ? row : tokens - 1;
@@ -94,20 +147,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       *(bf16x8*)(Vs + key * VSB + (CH + c) * 16) = z;
     }
   }
-  // Q fragments of the wave's first query tile go out while K / V are still in flight; the next tile's are fetched
-  // behind the current tile's QK^T (software pipeline: no query load is ever waited for at the top of a tile)
-  const bf16* qbase = (CLS_ONLY ? qsrc + (size_t)img * q_img_stride : qsrc + img_row * ld) + head * DH;
-  auto load_q = [&](int qt, bf16x8 (&dst)[KS]) {
-    const int q = qt * 32 + l31;
-    const int qc = q < tokens ? q : tokens - 1;
-    const bf16* qp = qbase + (size_t)qc * q_ld + 8 * lh;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) dst[s] = *(const bf16x8*)(qp + 16 * s);
-  };
-  bf16x8 qnext[KS];
-  if (wave < (CLS_ONLY ? 1 : NT)) load_q(wave, qnext);
-  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (SPLIT) {
+    wait_q(qnext, std::integral_constant<int, NT>{});               // Q and K have landed, V may still be in flight
+    __builtin_amdgcn_s_waitcnt(0x0F70 | NT);                        // the same wait, visible to the compiler's bookkeeping
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 
   // per-lane constants of the transposed V read: 16-lane group -> 16 d_h columns, lane 4q+p -> row q, cols 4p..
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
@@ -115,12 +163,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const int v_sw = DMA64 ? ((tr_q >> 1) & 1) : 0;        // swizzle bit of this lane's V rows (row bit 1 == tr_q bit 1)
   const int k_sw = DMA64 ? ((l31 >> 1) & 7) : 0;
 
-  for (int qt = wave; qt < (CLS_ONLY ? 1 : NT); qt += 4) {   // wave-uniform trip count: EXEC stays full
+  // One 32-query tile.  FIRST (SPLIT flow only): the wave's first tile, peeled out of the loop below so that the wait
+  // for V and its barrier are straight-line code — the compiler's own wait bookkeeping then knows the LDS-DMA has
+  // drained and adds nothing in later tiles (a wait it places there also waits for the previous tile's output stores).
+  auto tile = [&](const int qt, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
     const int q = qt * 32 + l31;
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = qnext[s];
-    if (!CLS_ONLY && qt + 4 < NT) load_q(qt + 4, qnext);
+    if constexpr (SPLIT) { if (qt + 4 < NT) load_q_asm(qt + 4, qnext); }
+    else if (!CLS_ONLY && qt + 4 < NT) load_q(qt + 4, qnext);
 
     f32x16 sacc[NT];
 #pragma unroll
@@ -164,6 +217,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const float inv = 1.0f / sum;
 
     // ---- O^T = V^T P^T
+    if constexpr (FIRST)                 // NT >= 4: all four waves get here exactly once.  Tied to the row sum: the
+      // wait must not be scheduled above the softmax (a memory clobber alone orders only the LDS reads)
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : "+v"(sum) :: "memory");
     f32x16 oacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -191,6 +247,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       }
     }
     // ---- store
+    if constexpr (SPLIT) {               // next tile's Q (issued a whole tile ago); never a wait for the previous stores
+      if (qt + 4 < NT) wait_q(qnext, std::integral_constant<int, 0>{});
+    }
     if constexpr (DMA64 && !CLS_ONLY) {
       // through a wave-private [32 queries][128 B] LDS tile (chunk ^= row & 7), so that every global store is a whole
       // 128-byte row segment of 8 lanes x 16 B instead of 8 bytes per lane at a row stride
@@ -234,5 +293,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
           }
         }
     }
+  };
+  if constexpr (SPLIT) {
+    tile(wave, std::true_type{});
+    for (int qt = wave + 4; qt < NT; qt += 4) tile(qt, std::false_type{});
+  } else {
+    for (int qt = wave; qt < (CLS_ONLY ? 1 : NT); qt += 4) tile(qt, std::false_type{});   // wave-uniform trip count: EXEC stays full
   }
 }
