@@ -301,3 +301,201 @@ __global__ __launch_bounds__(256, (DH == 64 ? 2 : 1)) void attn_fwd_kernel(const
     for (int qt = wave; qt < (CLS_ONLY ? 1 : NT); qt += 4) tile(qt, std::false_type{});   // wave-uniform trip count: EXEC stays full
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// d_h = 64, full attention, persistent form: ONE 8-wave workgroup per CU walks the (image, head) items
+// `blockIdx.x, blockIdx.x + gridDim.x, ...`.  K and V are double-buffered in LDS (2 x 2 x NT*32 rows x 128 B) and
+// wave 7 is the producer: right after the barrier that starts item i it issues the whole LDS-DMA of item i + 1 into
+// the other buffer, so the loads of the next item are in flight during ALL of this item's arithmetic (the one-item-per-
+// workgroup kernel above can only overlap loads and arithmetic across the two workgroups of a CU).  Waves 0..NT-1 are
+// the consumers, one 32-query tile each per item — the 2,2,2,1 tile split of the four-wave kernel is gone — and their
+// next Q fragments are fetched a whole item ahead.  One s_barrier per item:
+//     producer:  [DMA(i) landed: vmcnt(0)]  B(i)  issue DMA(i+1) -> buf[(i+1)&1]
+//     consumer:  [item i-1 finished]        B(i)  tile(i) from buf[i&1]
+// buf[(i+1)&1] held item i-1, which every consumer has finished before it arrives at B(i).
+// The per-tile arithmetic is the instruction-for-instruction order of attn_fwd_kernel<64, NT, false> (same MFMA
+// accumulation order, same softmax sum order): the outputs are bit-identical.
+template <int NT>
+__global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
+                                                               int tokens, int dim, int heads, int n_items, float scale, RowMap rm) {
+  static_assert(NT >= 1 && NT <= 7, "one consumer wave per query tile, wave 7 produces");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = 4, DT = 2, NKEY = NT * 32, KV = NKEY * 128, BUF = 2 * KV;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int G = gridDim.x;
+
+  auto row0_of = [&](int it, int& head) -> size_t { const int img = it / heads; head = it - img * heads; return (size_t)row_of(rm, img); };
+
+  // ---- producer side
+  auto issue = [&](int it, int b) {
+    int head; const size_t r0 = row0_of(it, head);
+    const bf16* base = qkv + r0 * ld + head * 64;
+    char* Kd = smem + b * BUF;
+    char* Vd = Kd + KV;
+    const int c = lane & 7;
+#pragma unroll 4
+    for (int piece = 0; piece < NT * 4; ++piece) {
+      const int row = piece * 8 + (lane >> 3);
+      const int rc = row < tokens ? row : tokens - 1;
+      glds16(base + (size_t)rc * ld + dim + ((c ^ ((row >> 1) & 7)) << 3), Kd + piece * 1024);
+    }
+#pragma unroll 4
+    for (int piece = 0; piece < NT * 4; ++piece) {
+      const int row = piece * 8 + (lane >> 3);
+      const int rc = row < tokens ? row : tokens - 1;
+      glds16(base + (size_t)rc * ld + 2 * dim + ((c ^ (((row >> 1) & 1) << 2)) << 3), Vd + piece * 1024);
+    }
+  };
+
+  // ---- consumer side: Q fragments by inline asm (explicit waits tied to the registers, see wait_q)
+  auto load_q_asm = [&](int it, bf16x8 (&dst)[KS]) {
+    int head; const size_t r0 = row0_of(it, head);
+    const int q = wave * 32 + l31;
+    const int qc = q < tokens ? q : tokens - 1;
+    const bf16* qp = qkv + (r0 + qc) * ld + head * 64 + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f32x4 t;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(t) : "v"(qp + 16 * s) : "memory");
+      dst[s] = __builtin_bit_cast(bf16x8, t);
+    }
+  };
+  auto wait_q0 = [&](bf16x8 (&dst)[KS]) {          // s_waitcnt vmcnt(0) that the uses of dst[] cannot move above
+    f32x4 t0 = __builtin_bit_cast(f32x4, dst[0]), t1 = __builtin_bit_cast(f32x4, dst[1]);
+    f32x4 t2 = __builtin_bit_cast(f32x4, dst[2]), t3 = __builtin_bit_cast(f32x4, dst[3]);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) :: "memory");
+    dst[0] = __builtin_bit_cast(bf16x8, t0); dst[1] = __builtin_bit_cast(bf16x8, t1);
+    dst[2] = __builtin_bit_cast(bf16x8, t2); dst[3] = __builtin_bit_cast(bf16x8, t3);
+  };
+
+  const bool consumer = (wave < NT);
+  int it = blockIdx.x;
+  // The producer's loop is separate code and returns: no LDS-DMA instruction lies on a consumer's control-flow path, so
+  // the compiler's wait bookkeeping never places a vmcnt wait (which would also wait for the consumer's own next-Q
+  // loads and previous stores) in front of the consumers' LDS reads.
+  if (wave == 7) {
+    if (it < n_items) issue(it, 0);
+    for (int b = 0; it < n_items; it += G, b ^= 1) {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (it + G < n_items) issue(it + G, b ^ 1);
+    }
+    return;
+  }
+  bf16x8 qnext[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qnext[s][j] = (bf16)0.f;
+  if (consumer && it < n_items) { load_q_asm(it, qnext); wait_q0(qnext); }
+
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
+  const int v_lane_off = (4 * lh + tr_q) * 128 + (16 * tr_g + 4 * tr_p) * 2;
+  const int v_sw = (tr_q >> 1) & 1;
+  const int k_sw = (l31 >> 1) & 7;
+  char* const ost = smem + 2 * BUF + (wave < 7 ? wave : 0) * 4096;
+
+  for (int b = 0; it < n_items; it += G, b ^= 1) {     // workgroup-uniform trip count: every wave meets every barrier
+    asm volatile("s_barrier" ::: "memory");
+    if (!consumer) continue;
+
+    const char* Ks = smem + b * BUF;
+    const char* Vs = Ks + KV;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = qnext[s];
+    const bool more = it + G < n_items;
+    if (more) load_q_asm(it + G, qnext);
+
+    f32x16 sacc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[kt][i] = 0.f;
+      const char* kp = Ks + (kt * 32 + l31) * 128;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 kf = *(const bf16x8*)(kp + (((2 * s + lh) ^ k_sw) << 4));
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (kt == NT - 1) {
+          const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+          if (key >= tokens) sacc[kt][i] = -INFINITY;
+        }
+        mx = fmaxf(mx, sacc[kt][i]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float c2 = scale * 1.44269504088896340736f;
+    const float mc = -mx * c2;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][i], c2, mc));
+        sacc[kt][i] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s2 + j];
+        const char* vp = Vs + (kt * 32 + 16 * s2) * 128 + v_lane_off;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(vp + (dt ^ v_sw) * 64));
+          const bf16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(vp + (dt ^ v_sw) * 64 + 8 * 128));
+          bf16x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { vf[j] = v1[j]; vf[4 + j] = v2[j]; }
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+      }
+    }
+    // next item's Q (issued a whole tile ago) and, older still, the previous item's stores
+    if (more) wait_q0(qnext);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 o4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] = (bf16)(oacc[dt][4 * g4 + j] * inv);
+        *(bf16x4*)(ost + l31 * 128 + (((dt * 4 + g4) ^ (l31 & 7)) << 4) + lh * 8) = o4;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bf16x8 ov[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int r = r4 * 8 + (lane >> 3);
+      ov[r4] = *(const bf16x8*)(ost + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int head; const size_t r0 = row0_of(it, head);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int qq = wave * 32 + r4 * 8 + (lane >> 3);
+      if (qq < tokens) *(bf16x8*)(out + (r0 + qq) * ldo + head * 64 + (lane & 7) * 8) = ov[r4];
+    }
+  }
+}

@@ -216,6 +216,24 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
   }
   ProfScope ps(e, SSP2_K_ATTN);
   const int D = e->d.dim, ld = 3 * D;
+  if constexpr (DH == 64 && !CLS && NT >= 4 && NT <= 7) {
+    // persistent producer / consumer form (attn.hip.h); SSP2_ATTN_PERSIST=0 keeps the one-item-per-workgroup kernel
+    const char* pv = getenv("SSP2_ATTN_PERSIST");              // read per launch: the A/B test flips it inside one process
+    if (!pv || atoi(pv) != 0) {
+      constexpr int psmem = 2 * 2 * NT * 32 * 128 + 7 * 4096;
+      static bool pattr_done = false;
+      if (!pattr_done) {
+        HIPCHK(hipFuncSetAttribute((const void*)attn64_persist_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, psmem));
+        pattr_done = true;
+      }
+      const long items = (long)e->d.heads * n;
+      if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
+      hipLaunchKernelGGL((attn64_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
+  }
   if (CLS)   // q from the compact CLS projection, only row 0 kept, compact [n, D] output
     hipLaunchKernelGGL((attn_fwd_kernel<DH, NT, true>), dim3(e->d.heads, n), dim3(256), smem, e->stream, e->qkvbuf, ld, e->q_cls,
                        (size_t)D, 0, e->o_cls, (size_t)D, D, e->tokens, D, 1.0f / sqrtf((float)DH), rm);

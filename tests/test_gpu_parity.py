@@ -383,6 +383,52 @@ def test_cls_only_tail_is_bit_identical_to_full_last_block(gpu, cfg):
         assert torch.equal(lt, lf) and torch.equal(pt, pf) and int(ct) == int(cf)
 
 
+@pytest.mark.parametrize("cfg,img", [("vit_small_patch16_224_d2", 224), ("vit_small_patch16_224_d2", 192)])
+def test_persistent_attention_is_bit_identical_to_the_one_item_kernel(gpu, cfg, img):
+    """d_h = 64 attention runs as a persistent producer / consumer kernel (attn64_persist_kernel: double-buffered K/V,
+    one query tile per wave); SSP2_ATTN_PERSIST=0 routes the same launch to attn_fwd_kernel.  Same per-tile arithmetic
+    order => the residual stream after two blocks must agree BIT FOR BIT: for item counts below, equal to a ragged
+    multiple of, and far above the CU count, in the contiguous and in the slab row layout, for 197 tokens (7 query
+    tiles) and 145 tokens (5 tiles: two idle waves that only meet the barriers)."""
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights(cfg, classes=10, seed=11, std=0.05, eps=1e-6, bias_std=0.02)
+    if img != 224:
+        w["img"] = img
+        ntok = (img // 16) ** 2 + 1
+        w["pos"] = w["pos"][:, :ntok, :].contiguous()
+    eng = VitEngine(w, max_images=192)
+    g = torch.Generator().manual_seed(5)
+    old = os.environ.get("SSP2_ATTN_PERSIST")
+    try:
+        for n, group in ((1, 0), (43, 0), (97, 0), (192, 0), (192, 64), (150, 64)):
+            px = torch.randn(n, 3, img, img, generator=g).to(gpu)
+            outs, scs = [], []
+            ntok = eng.tokens
+            if group:      # slab layout: only the rows of real images are defined
+                mpad = eng.rows(group, group)
+                valid = torch.cat([torch.arange(s0 * mpad, s0 * mpad + min(group, n - s0 * group) * ntok)
+                                   for s0 in range((n + group - 1) // group)]).to(gpu)
+            else:
+                valid = torch.arange(n * ntok, device=gpu)
+            for flag in ("1", "0"):
+                os.environ["SSP2_ATTN_PERSIST"] = flag
+                x = eng.embed(px, group=group)
+                sc = eng.layers(x, n, score_site="pre_gelu", score_group=group) if group else eng.layers(x, n)
+                torch.cuda.synchronize()
+                outs.append(x[valid].clone())
+                scs.append(None if sc is None else sc.clone())
+            assert torch.isfinite(outs[0]).all()
+            assert torch.equal(outs[0], outs[1]), f"n={n} group={group}"
+            if group:
+                assert torch.equal(scs[0], scs[1])
+    finally:
+        if old is None:
+            os.environ.pop("SSP2_ATTN_PERSIST", None)
+        else:
+            os.environ["SSP2_ATTN_PERSIST"] = old
+
+
 @pytest.mark.parametrize("cfg,layout", [("vit_huge_patch14_224_d2", "timm"), ("vit_large_patch16_224_d2", "hf"),
                                         ("vit_small_patch16_224_d2", "timm")])
 def test_other_geometries_vs_oracle(gpu, cfg, layout):
