@@ -313,8 +313,21 @@ __global__ __launch_bounds__(256, (DH == 64 ? 2 : 1)) void attn_fwd_kernel(const
 //     producer:  [DMA(i) landed: vmcnt(0)]  B(i)  issue DMA(i+1) -> buf[(i+1)&1]
 //     consumer:  [item i-1 finished]        B(i)  tile(i) from buf[i&1]
 // buf[(i+1)&1] held item i-1, which every consumer has finished before it arrives at B(i).
+// Measured with tools/attn_bench.hip (-DATTN_STAMPS): the item time of a SIMD's two consumer waves is the SUM of their
+// MFMA and VALU phases (11 k ticks per item = 2 x 5.2 k), DMA(i+1) has landed ~4 k ticks before the consumers finish
+// item i: the kernel is bound by the waves' dependent MFMA -> softmax -> MFMA chains at two waves per SIMD (112
+// accumulator registers per wave allow no third), not by HBM.  Replacing the barrier with LDS flags (landed / done
+// counters, waves free to drift apart) was tried: the older wave of each SIMD then runs a whole item ahead, waits for
+// data gated by the younger one, and the item time is unchanged (155.8 vs 158.2 us on 512 images) — not kept.
 // The per-tile arithmetic is the instruction-for-instruction order of attn_fwd_kernel<64, NT, false> (same MFMA
 // accumulation order, same softmax sum order): the outputs are bit-identical.
+#ifdef ATTN_STAMPS
+__device__ unsigned long long* attn_stamp_ptr;    // [8 waves][256 slots] of workgroup 0 (tools/attn_bench.hip)
+#define ASTAMP(slot) do { if (blockIdx.x == 0 && lane == 0 && (slot) < 256) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); attn_stamp_ptr[wave * 256 + (slot)] = t_; } } while (0)
+#else
+#define ASTAMP(slot) do {} while (0)
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                                int tokens, int dim, int heads, int n_items, float scale, RowMap rm) {
@@ -377,9 +390,13 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
   // loads and previous stores) in front of the consumers' LDS reads.
   if (wave == 7) {
     if (it < n_items) issue(it, 0);
-    for (int b = 0; it < n_items; it += G, b ^= 1) {
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int b = 0, n = 0; it < n_items; it += G, b ^= 1, ++n) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ASTAMP(n * 4 + 0);                                     // DMA(i) landed
+      asm volatile("s_barrier" ::: "memory");
+      ASTAMP(n * 4 + 1);                                     // B(i) passed
       if (it + G < n_items) issue(it + G, b ^ 1);
+      ASTAMP(n * 4 + 2);                                     // DMA(i+1) issued
     }
     return;
   }
@@ -396,8 +413,10 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
   const int k_sw = (l31 >> 1) & 7;
   char* const ost = smem + 2 * BUF + (wave < 7 ? wave : 0) * 4096;
 
-  for (int b = 0; it < n_items; it += G, b ^= 1) {     // workgroup-uniform trip count: every wave meets every barrier
+  for (int b = 0, n = 0; it < n_items; it += G, b ^= 1, ++n) {     // workgroup-uniform trip count: every wave meets every barrier
+    ASTAMP(n * 4 + 0);                                       // arrived at B(i)
     asm volatile("s_barrier" ::: "memory");
+    ASTAMP(n * 4 + 1);                                       // B(i) passed
     if (!consumer) continue;
 
     const char* Ks = smem + b * BUF;
@@ -444,6 +463,10 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
         sum += e;
       }
     sum += __shfl_xor(sum, 32);
+#ifdef ATTN_STAMPS
+    asm volatile("" : "+v"(sum));
+    ASTAMP(n * 4 + 2);                                       // softmax sum known
+#endif
     const float inv = 1.0f / sum;
 
     f32x16 oacc[DT];
@@ -474,6 +497,10 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
     }
     // next item's Q (issued a whole tile ago) and, older still, the previous item's stores
     if (more) wait_q0(qnext);
+#ifdef ATTN_STAMPS
+    asm volatile("" : "+v"(oacc[0]), "+v"(oacc[1]));
+    ASTAMP(n * 4 + 3);                                       // P V done, Q of the next item here
+#endif
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
