@@ -147,6 +147,12 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 
   const int nk = g.K / GEMM_BK;
   int tile = wg;
+#ifdef GEMM_STAGGER
+  // experiment: every second workgroup of an XCD starts g.group_m x 1024 cycles late, so that the residual epilogues'
+  // HBM bursts of the two halves interleave (timing builds of tools/gemm_bench only)
+  if (EPI == EPI_RESID && ((blockIdx.x >> 3) & 1))
+    for (int c = 0; c < g.group_m; ++c) __builtin_amdgcn_s_sleep(16);
+#endif
   if (tile < ntiles) {
     set_tile(tile);
     bias_next = g.bias[n0 + wn * 64 + lane];
