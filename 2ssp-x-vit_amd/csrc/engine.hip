@@ -151,6 +151,7 @@ template <int EPI, int SCORE = 0>
 static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
+  g.group_m = 0;                 // plain N-fastest tile order (group_m means column groups here, see gemm256.hip.h)
   static bool attr_done = false;
   if (!attr_done) {
     HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS));

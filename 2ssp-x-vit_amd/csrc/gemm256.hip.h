@@ -121,7 +121,24 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   int m0 = 0, n0 = 0;
   float bias_next = 0.f;                                // bias[n0 + wn*64 + lane] of the tile being prefetched
   auto set_tile = [&](int tile) {
-    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;   // N fastest: neighbours share the A panel
+    int tm, tn;
+    const int gn = g.group_m % 100, gm = g.group_m / 100;          // group_m = 100 * GM + GN (0: plain order)
+    if (gn > 0 && gn < g.tiles_n) {
+      // Super-tiles for the 4 MiB L2 of an XCD: blocks of GM row panels (all of them if GM = 0); inside a block column
+      // groups of GN tiles, inside a group N fastest.  An XCD's 32 concurrent tiles then touch GN weight panels instead
+      // of all of them, and the next column group of the block re-reads the block's A panels from L2 / Infinity Cache.
+      const int bm = gm > 0 ? gm : g.tiles_m;
+      const int per_block = bm * g.tiles_n;
+      const int mb = tile / per_block, r = tile - mb * per_block;
+      const int left_m = g.tiles_m - mb * bm, rows = left_m < bm ? left_m : bm;
+      const int per_group = rows * gn;
+      const int cg = r / per_group, r2 = r - cg * per_group;
+      const int left_n = g.tiles_n - cg * gn, gw = left_n < gn ? left_n : gn;
+      const int tr = r2 / gw;
+      tm = mb * bm + tr; tn = cg * gn + (r2 - tr * gw);
+    } else {
+      tm = tile / g.tiles_n; tn = tile - tm * g.tiles_n;            // N fastest: neighbours share the A panel
+    }
     m0 = tm * C::BM; n0 = tn * C::BN;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
