@@ -114,6 +114,9 @@ def main():
                     help="candidate-major search (one launch per candidate and block) instead of the layer-major one, "
                          "in which all candidates under way run a block in ONE launch (engine workspace for "
                          "(depth-1) x eval images)")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="keep the batches in pinned HOST memory, as a dataloader hands them over: every step then pays "
+                         "the PCIe copy of 602 KB per image (the PCIe-inclusive rate of DESIGN.md; never the default)")
     ap.add_argument("--two-streams", action="store_true",
                     help="run stage 1 and a share of the search candidates on a second HIP stream with its own engine "
                          "workspace (5 %% faster end to end; per-launch durations then include the share of the "
@@ -168,6 +171,9 @@ def main():
         x = eng.embed(px); eng.layers(x, args.batch)
         _, pred, _ = eng.head(x, args.batch, want_pred=True)
         evalb.append({"pixel_values": px, "labels": pred.long()})     # teacher labels: dense model's own argmax
+    if args.host_inputs:
+        calib = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in calib]
+        evalb = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in evalb]
     calib_loader, eval_loader = make_loader(calib, rank, world), make_loader(evalb, rank, world)
     n_eval = args.eval_batches * args.batch
 
@@ -244,7 +250,8 @@ def main():
             "metric": "2ssp_prune_image_forwards_per_sec", "value": round(value, 1), "unit": "image-forwards/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic, pinned host batches copied over PCIe inside the timed region" if args.host_inputs else "synthetic",
             "config": {"workload": f"{args.model}, {args.calib} calib images/GPU, full 2SSP @ {args.target} "
                                    f"(K={plan.blocks_to_prune} blocks, t={plan.per_block_neurons_to_prune} neurons), "
                                    f"one-shot depth search over {n_eval} eval images/GPU, batch {args.batch}",
