@@ -35,6 +35,30 @@ def _resolve(engine, min_images: int):
     return engine(min_images) if callable(engine) else engine
 
 
+_COPY_STREAMS = {}
+
+
+def _to_device(t: torch.Tensor, device, dtype) -> torch.Tensor:
+    """Batch tensor -> device.  A tensor that already lives there is passed through.  A HOST tensor (what the
+    reference's dataloaders yield, src/vit_pruning.py:177) is copied on a per-device COPY STREAM: the host runs ahead of
+    the GPU, so the copies of later batches overlap the forward of earlier ones instead of sitting between the
+    kernels of the compute stream (pinned memory makes them asynchronous; pageable memory still works, staged by the
+    runtime).  The compute stream waits for the copy's event before the first use."""
+    device = torch.device(device)
+    if t.device == device or device.type != "cuda":
+        return t.to(device, dtype, non_blocking=True)
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    cs = _COPY_STREAMS.get(key)
+    if cs is None:
+        cs = _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+    cur = torch.cuda.current_stream(device)
+    with torch.cuda.stream(cs):
+        out = t.to(device, dtype, non_blocking=True)
+    cur.wait_stream(cs)
+    out.record_stream(cur)
+    return out
+
+
 class _Chunker:
     """Packs consecutive dataloader batches into one device forward of up to `capacity` images.
 
@@ -56,8 +80,8 @@ class _Chunker:
                 or len(self.items) >= self.max_batches)
 
     def add(self, idx, px, labels=None):
-        self.items.append((idx, px.to(self.device, torch.float32, non_blocking=True),
-                           None if labels is None else labels.to(self.device, torch.int64, non_blocking=True)))
+        self.items.append((idx, _to_device(px, self.device, torch.float32),
+                           None if labels is None else _to_device(labels, self.device, torch.int64)))
         self.count += int(px.size(0))
 
     def take(self):
@@ -184,8 +208,8 @@ def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images):
         if eng is None:
             eng = _resolve(engine, max(chunk_images, int(px.size(0))))
         cap = min(eng.max_images, chunk_images) if chunk_images > 0 else min(eng.max_images, int(px.size(0)))
-        px_buf.append(px.to(eng.device, torch.float32, non_blocking=True))
-        lb_buf.append(labels.to(eng.device, torch.int64, non_blocking=True))
+        px_buf.append(_to_device(px, eng.device, torch.float32))
+        lb_buf.append(_to_device(labels, eng.device, torch.int64))
         count += int(px.size(0))
         while count >= cap:
             yield cut(cap)
