@@ -49,6 +49,21 @@ def pmc_traffic():
         return None
 
 
+def pmc_mfma():
+    """Matrix-pipe busy fraction (of the cycles the part actually ran) and shader clock of the fc1 search kernel, from the
+    newest committed PMC pass (scripts/pmc_mfma.py -> profiles/r<round>_<tag>_pmc_mfma.json); None when absent."""
+    import glob
+    try:
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))[-1]
+        with open(newest) as f:
+            ks = json.load(f)["kernels"]
+        k = [r for r in ks if "gemm256_bf16_kernel<2, 0>" in r["kernel"]][0]
+        return {"mfma_busy_frac_of_cycles": k["mfma_util_of_cycles"], "shader_clock_ghz": k["shader_clock_ghz"],
+                "source": os.path.basename(newest)}
+    except Exception:
+        return None
+
+
 class _MetaBatch(dict):
     """Placeholder for a batch owned by another rank: only its size is ever read."""
 
@@ -270,7 +285,7 @@ def main():
             lm = f", x 1..{depth - 1} in the layer-major search" if args.batch_candidates else ""
             line["roofline"] = {"bound": "mfma", "kernel": "fc1 GEMM family: gemm256_bf16_kernel<EPI_FC1,SCORE> persistent 256x256 (stage 1: + fused activation-L2 partials; search passes: SCORE=0) and gemm_bf16_kernel<EPI_FC1> 128x128 (CLS tail); bias + erf-GELU fused",
                                 "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                                "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(), "pmc": pmc_mfma(),
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
                                 "flops_per_launch_avg": prof.flops / prof.launches,
                                 "shapes": f"[{eng.rows(min(args.calib, args.calib_chunk or args.batch), args.batch)} | {(args.eval_chunk or n_eval) * tokens} | {n_eval}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk{lm} | CLS tail)"}
