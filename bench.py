@@ -134,7 +134,7 @@ def main():
                          "the PCIe copy of 602 KB per image (the PCIe-inclusive rate of DESIGN.md; never the default)")
     ap.add_argument("--two-streams", action="store_true",
                     help="run stage 1 and a share of the search candidates on a second HIP stream with its own engine "
-                         "workspace (5 %% faster end to end; per-launch durations then include the share of the "
+                         "workspace (2-5 %% faster end to end; per-launch durations then include the share of the "
                          "machine lent to the other stream, so the roofline object is not a clean kernel figure)")
     args = ap.parse_args()
 
