@@ -130,7 +130,12 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
             if ch is not None and ch.items:
                 flush()
             eng = _resolve(engine, max(chunk_images, n))
-            ch = _Chunker(min(eng.max_images, max(chunk_images, n)), eng.device, max_batches=MAX_SLABS)
+            cap = min(eng.max_images, max(chunk_images, n))
+            if px.device.type == "cpu" and torch.device(eng.device).type == "cuda" and cap >= 4 * n:
+                # host batches: two launches instead of one, so that the copies of the second half overlap the forward
+                # of the first (scores do not depend on the packing: every batch is its own slab)
+                cap = (cap // 2) // n * n
+            ch = _Chunker(cap, eng.device, max_batches=MAX_SLABS)
         if ch.full_for(n):
             flush()
         ch.add(i, px)
