@@ -317,9 +317,10 @@ __global__ __launch_bounds__(256, (DH == 64 ? 2 : 1)) void attn_fwd_kernel(const
 // MFMA and VALU phases (11 k ticks per item = 2 x 5.2 k), DMA(i+1) has landed ~4 k ticks before the consumers finish
 // item i: not HBM-bound.  Three different organisations (this one, the one-item kernel, and a two-pass tile with 14
 // waves per CU kept in tools/attn_bench.hip) and a head-major q/k/v layout all land on 6.1-6.9 us per item per CU: the
-// common term is the softmax's VALU issue (per 32-query tile ~700 VALU + 112 v_exp, 1.75 tiles per SIMD per item).  Replacing the barrier with LDS flags (landed / done
-// counters, waves free to drift apart) was tried: the older wave of each SIMD then runs a whole item ahead, waits for
-// data gated by the younger one, and the item time is unchanged (155.8 vs 158.2 us on 512 images) — not kept.
+// common term is the softmax's VALU issue (per 32-query tile ~700 VALU + 112 v_exp, 1.75 tiles per SIMD per item).
+// Replacing the barrier with LDS flags (landed / done counters, waves free to drift apart) was tried: the older wave
+// of each SIMD then runs a whole item ahead, waits for data gated by the younger one, and the item time is unchanged
+// (155.8 vs 158.2 us on 512 images) — not kept.
 // The per-tile arithmetic is the instruction-for-instruction order of attn_fwd_kernel<64, NT, false> (same MFMA
 // accumulation order, same softmax sum order): the outputs are bit-identical.
 #ifdef ATTN_STAMPS
