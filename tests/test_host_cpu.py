@@ -211,3 +211,30 @@ def test_empty_and_limited_loaders_like_reference():
     assert vp.evaluate_top1(m, batches, device="cuda", max_batches=0) == 0.0
     base, cand, total = vp.depth_search_counts(m, [], "cuda", 5)
     assert (base, cand, total) == (0, [0, 0, 0, 0], 0)
+
+
+def test_bench_reads_the_committed_pmc_summaries():
+    """bench.py fills roofline.traffic and roofline.pmc from the newest committed rocprofv3 PMC summaries (counters
+    cannot be read from inside the process): the files under profiles/ must keep the fields it reads."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)                      # main() is guarded: nothing runs
+    traffic = bench.pmc_traffic()
+    assert isinstance(traffic, int) and traffic > 100e6                      # bytes per fc1 launch
+    pmc = bench.pmc_mfma()
+    assert pmc is not None and 0.2 < pmc["mfma_busy_frac_of_cycles"] < 1.0 and 1.0 < pmc["shader_clock_ghz"] < 2.6
+    assert os.path.exists(os.path.join(root, "profiles", pmc["source"]))
+
+
+def test_host_batches_pass_through_on_a_cpu_engine():
+    """core._to_device: the copy stream is for host -> GPU only; with a CPU device (the gloo tests' engines) tensors are
+    converted in place, same values and dtype."""
+    import torch
+    from ssp2vit import core
+    t = torch.arange(6, dtype=torch.float64).reshape(2, 3)
+    out = core._to_device(t, "cpu", torch.float32)
+    assert out.dtype == torch.float32 and out.device.type == "cpu" and torch.equal(out, t.float())
+    lab = torch.tensor([1, 2], dtype=torch.int32)
+    assert core._to_device(lab, torch.device("cpu"), torch.int64).dtype == torch.int64
