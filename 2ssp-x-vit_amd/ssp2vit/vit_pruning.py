@@ -39,11 +39,16 @@ def _get_encoder(vit_model):
 
 
 def _blocks(vit_model):
+    """(blocks, kind).  kind "hf" / "timm" are the two anatomies the reference duck-types over (:27-45); "hf5" is the
+    renamed layout of transformers >= 5 (`vit.layers[i].{attention.{q,k,v,o}_proj, mlp.fc1, mlp.fc2}`), on which the
+    reference itself raises AttributeError — accepted here because it is the only HF ViT installable today."""
     enc = _get_encoder(vit_model)
     if hasattr(enc, "layer"):
         return list(enc.layer), "hf"
     if hasattr(enc, "blocks"):
         return list(enc.blocks), "timm"
+    if hasattr(enc, "layers") and all(hasattr(b, "mlp") and hasattr(b.mlp, "fc1") for b in enc.layers):
+        return list(enc.layers), "hf5"
     raise AttributeError("Unsupported ViT model structure: expected encoder.layer or blocks")
 
 
@@ -51,7 +56,7 @@ def _gather_mlp_pairs(vit_model) -> List[Tuple[nn.Linear, nn.Linear]]:
     blocks, kind = _blocks(vit_model)
     if kind == "hf":
         return [(b.intermediate.dense, b.output.dense) for b in blocks]
-    return [(b.mlp.fc1, b.mlp.fc2) for b in blocks]
+    return [(b.mlp.fc1, b.mlp.fc2) for b in blocks]          # timm and hf5 name the pair alike
 
 
 def _get_hidden_and_inter_sizes(vit_model) -> Tuple[int, List[int]]:
@@ -73,7 +78,7 @@ def compute_actual_sparsity(before_params: int, after_params: int) -> float:
 
 
 def _attn_module(block, kind):
-    return getattr(block, "attention" if kind == "hf" else "attn", None)
+    return getattr(block, "attn" if kind == "timm" else "attention", None)
 
 
 def _model_stats(vit_model) -> ModelStats:
@@ -262,13 +267,21 @@ class TimmAttentionBypass(nn.Module):
         return torch.zeros_like(x)
 
 
+class HF5AttentionBypass(nn.Module):
+    """Zero-output attention for the transformers >= 5 layer, whose attention always returns the pair
+    (attn_output, attn_weights) and is called as `attention(hidden_states, attention_mask, **kwargs)`."""
+    def forward(self, hidden_states, attention_mask=None, *args, **kwargs):
+        return torch.zeros_like(hidden_states), None
+
+
 def _apply_bypass(vit_model, idx: int) -> None:
     blocks, kind = _blocks(vit_model)
-    enc = _get_encoder(vit_model)
     if kind == "hf" and hasattr(blocks[idx], "attention"):
-        enc.layer[idx].attention = HFAttentionBypass()
+        blocks[idx].attention = HFAttentionBypass()
+    elif kind == "hf5" and hasattr(blocks[idx], "attention"):
+        blocks[idx].attention = HF5AttentionBypass()
     elif kind == "timm" and hasattr(blocks[idx], "attn"):
-        enc.blocks[idx].attn = TimmAttentionBypass()
+        blocks[idx].attn = TimmAttentionBypass()
 
 
 @torch.no_grad()

@@ -96,6 +96,11 @@ def _f32(t) -> torch.Tensor:
     return t.detach().to("cpu", torch.float32).contiguous()
 
 
+def _bias_or_zeros(lin) -> torch.Tensor:
+    """nn.Linear bias, or zeros when the layer was built with bias=False (timm's qkv_bias=False)."""
+    return _f32(lin.bias) if getattr(lin, "bias", None) is not None else torch.zeros(lin.weight.shape[0])
+
+
 def detect_layout(model) -> str:
     """'timm' | 'hf' (transformers<5: vit.encoder.layer) | 'hf5' (transformers>=5: vit.layers)."""
     if hasattr(model, "blocks") and hasattr(model, "patch_embed"):
@@ -127,8 +132,8 @@ def from_module(model) -> Dict:
             w[f"ln1_g.{i}"], w[f"ln1_b.{i}"] = _f32(b.norm1.weight), _f32(b.norm1.bias)
             attn = getattr(b, "attn", None)
             if attn is not None and hasattr(attn, "qkv"):
-                w[f"qkv_w.{i}"], w[f"qkv_b.{i}"] = _f32(attn.qkv.weight), _f32(attn.qkv.bias)
-                w[f"proj_w.{i}"], w[f"proj_b.{i}"] = _f32(attn.proj.weight), _f32(attn.proj.bias)
+                w[f"qkv_w.{i}"], w[f"qkv_b.{i}"] = _f32(attn.qkv.weight), _bias_or_zeros(attn.qkv)
+                w[f"proj_w.{i}"], w[f"proj_b.{i}"] = _f32(attn.proj.weight), _bias_or_zeros(attn.proj)
             else:  # attention already replaced by a bypass (a6): zero weights + skip flag
                 w[f"attn_absent.{i}"] = True
             w[f"ln2_g.{i}"], w[f"ln2_b.{i}"] = _f32(b.norm2.weight), _f32(b.norm2.bias)
@@ -137,7 +142,12 @@ def from_module(model) -> Dict:
         w["lnf_g"], w["lnf_b"] = _f32(model.norm.weight), _f32(model.norm.bias)
         w["head_w"], w["head_b"] = _f32(model.head.weight), _f32(model.head.bias)
         eps = float(model.norm.eps)
-        heads = int(blocks[0].attn.num_heads) if hasattr(blocks[0].attn, "num_heads") else None
+        # the head count lives on the attention modules; block 0 may already be a bypass (the heuristic prunes it
+        # first), so take it from the first block that still has one, then from a config object
+        heads = next((int(b.attn.num_heads) for b in blocks if hasattr(getattr(b, "attn", None), "num_heads")), None)
+        if heads is None:
+            heads = getattr(getattr(model, "config", None), "num_attention_heads", None)
+            heads = None if heads is None else int(heads)
     elif layout == "hf":
         vit = model.vit if hasattr(model, "vit") else model
         emb = vit.embeddings
@@ -151,7 +161,7 @@ def from_module(model) -> Dict:
             sa = getattr(att, "attention", None)
             if sa is not None and hasattr(sa, "query"):
                 w[f"qkv_w.{i}"] = torch.cat([_f32(sa.query.weight), _f32(sa.key.weight), _f32(sa.value.weight)], 0)
-                w[f"qkv_b.{i}"] = torch.cat([_f32(sa.query.bias), _f32(sa.key.bias), _f32(sa.value.bias)], 0)
+                w[f"qkv_b.{i}"] = torch.cat([_bias_or_zeros(sa.query), _bias_or_zeros(sa.key), _bias_or_zeros(sa.value)], 0)
                 w[f"proj_w.{i}"], w[f"proj_b.{i}"] = _f32(att.output.dense.weight), _f32(att.output.dense.bias)
             else:
                 w[f"attn_absent.{i}"] = True
@@ -174,8 +184,8 @@ def from_module(model) -> Dict:
             a = l.attention
             if hasattr(a, "q_proj"):
                 w[f"qkv_w.{i}"] = torch.cat([_f32(a.q_proj.weight), _f32(a.k_proj.weight), _f32(a.v_proj.weight)], 0)
-                w[f"qkv_b.{i}"] = torch.cat([_f32(a.q_proj.bias), _f32(a.k_proj.bias), _f32(a.v_proj.bias)], 0)
-                w[f"proj_w.{i}"], w[f"proj_b.{i}"] = _f32(a.o_proj.weight), _f32(a.o_proj.bias)
+                w[f"qkv_b.{i}"] = torch.cat([_bias_or_zeros(a.q_proj), _bias_or_zeros(a.k_proj), _bias_or_zeros(a.v_proj)], 0)
+                w[f"proj_w.{i}"], w[f"proj_b.{i}"] = _f32(a.o_proj.weight), _bias_or_zeros(a.o_proj)
             else:
                 w[f"attn_absent.{i}"] = True
             w[f"ln2_g.{i}"], w[f"ln2_b.{i}"] = _f32(l.layernorm_after.weight), _f32(l.layernorm_after.bias)
@@ -192,7 +202,11 @@ def from_module(model) -> Dict:
     side = int(round(math.sqrt(n_tok - 1)))
     depth = sum(1 for k in w if k.startswith("ln1_g."))
     if heads is None:
-        heads = max(1, dim // 64)
+        if depth and all(w.get(f"attn_absent.{i}") for i in range(depth)):
+            heads = max(1, dim // 64)       # no attention left anywhere: the value is never used by a kernel
+        else:
+            raise AttributeError("cannot determine the number of attention heads: no block exposes attn.num_heads and "
+                                 "the model has no config.num_attention_heads")
     for i in range(depth):  # bypassed attention: supply zero weights, the engine skips the block anyway
         if w.get(f"attn_absent.{i}"):
             w[f"qkv_w.{i}"] = torch.zeros(3 * dim, dim); w[f"qkv_b.{i}"] = torch.zeros(3 * dim)

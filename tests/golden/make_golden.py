@@ -143,6 +143,44 @@ def vit_tiny_case():
           len(set(imps[0].float().tolist())))
 
 
+def vit_b16_case():
+    """BASELINE.json configs[1] geometry at a size the REAL reference finishes in about two minutes on 8 cores:
+    ViT-B/16, 1000 classes, fc1 rows spread x[1/4, 4] (the bench's weights), 2 x 32 images.  Stored: the reference's
+    bf16 stage-1 scores, the masks its mask step makes of them at the planner's t = 1120 (on the CLI's fp32 cast,
+    auto_2ssp.py:809), the teacher labels (dense-model argmax under the reference's autocast), the dense top-1 and the
+    depth-importance vector over those 64 images — plus the oracle's fp32-chain scores, so that the GPU test needs no
+    CPU forward at this size.  Weights and pixels are regenerated from seeds (346 MB of fp32 is not a fixture)."""
+    import copy
+    from oracle import ref_cpu
+    w = synthetic_weights("vit_base_patch16_224", classes=1000, seed=0, std=0.02, eps=1e-6, spread=4.0)
+    model = build_from_flat(w, "timm")
+    batches = make_batches(2, 32, 224, seed=1, model=model)
+    rec = {"weights_checksum": np.float64(sum(float(v.double().sum()) for v in w.values() if isinstance(v, torch.Tensor))),
+           "pixels_checksum": np.float64(sum(float(b["pixel_values"].double().sum()) for b in batches))}
+    for i, b in enumerate(batches):
+        rec[f"labels.{i}"] = b["labels"].numpy()
+    imps = ref_vp._compute_ffn_activation_importance(model, batches, device="cpu")
+    assert all(t.dtype == torch.bfloat16 for t in imps)
+    for i, t in enumerate(imps):
+        rec[f"s1_imp_bf16bits.{i}"] = bits(t)
+    res = quiet(ref_vp.prune_vit_mlp_width, copy.deepcopy(model), n_to_prune_per_block=[1120] * 12, min_remaining=512,
+                collect_masks=True, precomputed_importance=[x.to(torch.float32) for x in imps])
+    rec["mask.t1120"] = np.packbits(np.asarray(res["ffn_prune_masks"], dtype=np.uint8), axis=1)
+    rec["top1"] = np.float64(ref_vp.evaluate_top1(model, batches, device="cpu"))
+    iface = ref_mc.Auto2SSPInterface(model, batches, device="cpu", importance_mode="copy", batch_limit=5)
+    rec["att_imp"] = quiet(iface._compute_att_depth_importance).numpy()
+    sel = [int(i) for i in torch.argsort(torch.from_numpy(rec["att_imp"]))[:5]]          # auto_2ssp.py:857, K = 5
+    rec["s2_selected_k5"] = np.asarray(sorted(sel), dtype=np.int64)
+    o32 = ref_cpu.ffn_activation_importance(model, batches, chain="fp32")
+    for i, t in enumerate(o32):
+        rec[f"oracle_fp32.{i}"] = t.numpy()
+    ob = ref_cpu.ffn_activation_importance(model, batches)
+    assert all(torch.equal(a, b) for a, b in zip(ob, imps)), "oracle != reference at ViT-B/16"
+    np.savez_compressed(os.path.join(HERE, "vit_b16_2x32.npz"), **rec)
+    print(f"[golden] vit_b16_2x32: top1={rec['top1']:.4f} att_imp={rec['att_imp'].tolist()} selected={sorted(sel)} "
+          f"distinct bf16 scores in block 0: {len(set(imps[0].float().tolist()))}")
+
+
 def planner_cases():
     """plan_2ssp_allocation known answers on architecture-shaped modules (meta device: only numel is read)."""
     out = []
@@ -282,12 +320,16 @@ if __name__ == "__main__":
     if "--preprocess-only" in sys.argv:
         preprocess_cases()
         sys.exit(0)
+    if "--b16-only" in sys.argv:
+        vit_b16_case()
+        sys.exit(0)
     if "--artifacts-only" in sys.argv:
         artifact_tool_cases()
         sys.exit(0)
     tiny_case("timm", std=0.25)
     tiny_case("hf", std=0.25)
     vit_tiny_case()
+    vit_b16_case()
     planner_cases()
     heuristic_and_exports()
     artifact_tool_cases()

@@ -238,3 +238,68 @@ def test_host_batches_pass_through_on_a_cpu_engine():
     assert out.dtype == torch.float32 and out.device.type == "cpu" and torch.equal(out, t.float())
     lab = torch.tensor([1, 2], dtype=torch.int32)
     assert core._to_device(lab, torch.device("cpu"), torch.int64).dtype == torch.int64
+
+
+# ------------------------------------------------------------------------------------------ anatomy adapters
+def test_from_module_keeps_the_head_count_when_block_0_is_bypassed():
+    """The heuristic stage 2 prunes block 0 first; a bypass module has no num_heads.  d_h = 16 (4 heads of dim 64):
+    the old dim // 64 guess would have rebuilt the engine with ONE head."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp, weights as W
+    w, _, _ = load_tiny_golden("timm")
+    m = build_from_flat(w, "timm")
+    assert W.from_module(m)["heads"] == 4
+    vp._apply_bypass(m, 0)
+    flat = W.from_module(m)
+    assert flat["heads"] == 4 and flat["attn_absent.0"] is True and "attn_absent.1" not in flat
+    for i in range(1, 4):
+        vp._apply_bypass(m, i)
+    assert W.from_module(m)["heads"] >= 1                     # no attention left: any value, nothing reads it
+    # no block with num_heads and no config: refuse to guess
+    m2 = build_from_flat(w, "timm")
+    for b in m2.blocks:
+        del b.attn.num_heads
+    if hasattr(m2, "config"):
+        del m2.config
+    with pytest.raises(AttributeError):
+        W.from_module(m2)
+    # qkv_bias=False (timm option): zeros instead of a crash
+    m3 = build_from_flat(w, "timm")
+    m3.blocks[1].attn.qkv.bias = None
+    assert torch.equal(W.from_module(m3)["qkv_b.1"], torch.zeros(3 * 64))
+
+
+def test_transformers5_anatomy_plan_mask_step_and_bypass():
+    """The installed transformers (>= 5) names the encoder `vit.layers[i].{attention.{q,k,v,o}_proj, mlp.fc1, mlp.fc2}`.
+    The reference raises AttributeError on it; this build accepts it: planner, width prune (in-place
+    slicing), attention bypass with the pair-returning signature, and the flat-weight adapter, all on CPU."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import ViTConfig, ViTForImageClassification
+    from ssp2vit import vit_pruning as vp, weights as W
+    torch.manual_seed(0)
+    cfg = ViTConfig(hidden_size=64, num_hidden_layers=4, num_attention_heads=4, intermediate_size=128, image_size=32,
+                    patch_size=16, num_labels=10)
+    m = ViTForImageClassification(cfg).eval()
+    blocks, kind = vp._blocks(m)
+    if kind != "hf5":
+        pytest.skip("installed transformers still has the pre-5 anatomy")
+    assert len(blocks) == 4 and len(vp._gather_mlp_pairs(m)) == 4 and len(vp.count_block_params(m)) == 4
+    plan = vp.plan_2ssp_allocation(m, 0.3, min_remaining=16)
+    assert plan.num_blocks_total == 4 and 0 < plan.blocks_to_prune < 4 and plan.per_block_neurons_to_prune > 0
+    assert W.detect_layout(m) == "hf5" and W.score_site_for("hf5") == "post_gelu"
+    flat = W.from_module(m)
+    assert (flat["heads"], flat["depth"], flat["dim"], flat["classes"]) == (4, 4, 64, 10)
+    px = torch.randn(2, 3, 32, 32)
+    ref = m(pixel_values=px).logits
+    res = vp.prune_vit_mlp_width(m, n_to_prune_per_block=[40] * 4, min_remaining=16, strategy="l1", collect_masks=True)
+    assert all(sum(r) == 40 for r in res["ffn_prune_masks"]) and [l.mlp.fc1.out_features for l in m.vit.layers] == [88] * 4
+    assert m(pixel_values=px).logits.shape == ref.shape
+    out = vp.prune_vit_attention_blocks(m, sparsity=0.5, dataloader=None, importance_mode="heuristic",
+                                        show_progress=False, num_to_prune=2)
+    assert out["pruned_indices"] == [0, 1]
+    assert isinstance(m.vit.layers[0].attention, vp.HF5AttentionBypass)
+    lg = m(pixel_values=px).logits                              # the bypass speaks the layer's (output, weights) protocol
+    assert lg.shape == (2, 10) and torch.isfinite(lg).all()
+    flat2 = W.from_module(m)
+    assert flat2["attn_absent.0"] and flat2["attn_absent.1"] and flat2["heads"] == 4
+    assert flat2["fc1_w.2"].shape == (88, 64) and flat2["fc2_w.2"].shape == (64, 88)

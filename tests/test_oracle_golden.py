@@ -115,3 +115,29 @@ def test_act_l2_f64_statement():
     act = rng.standard_normal((3, 5, 7)).astype(np.float32)
     ref = torch.linalg.vector_norm(torch.from_numpy(act).double(), ord=2, dim=1).sum(0).numpy()
     assert np.allclose(ref_cpu.act_l2_accum_f64(act), ref, rtol=1e-14)
+
+
+def test_vit_b16_headline_geometry_pins_the_oracle():
+    """BASELINE.json configs[1] geometry (ViT-B/16, 1000 classes, spread fc1 rows), 2 x 32 images: the oracle's bf16
+    stage-1 scores equal the REAL reference's bit for bit, its mask step reproduces the reference's masks at the
+    planner's t = 1120, and its fp32-chain scores are the ones the GPU test compares the engine with (committed, so
+    the GPU box needs no CPU forward at this size).  ~10 s on 8 cores."""
+    import os
+    from ssp2vit.weights import synthetic_weights
+    z = dict(np.load(os.path.join(GOLDEN, "vit_b16_2x32.npz")))
+    w = synthetic_weights("vit_base_patch16_224", classes=1000, seed=0, std=0.02, eps=1e-6, spread=4.0)
+    chk = sum(float(v.double().sum()) for v in w.values() if isinstance(v, torch.Tensor))
+    assert chk == float(z["weights_checksum"]), "seeded weight generation drifted"
+    g = torch.Generator().manual_seed(1)
+    batches = [{"pixel_values": torch.randn(32, 3, 224, 224, generator=g)} for _ in range(2)]
+    assert sum(float(b["pixel_values"].double().sum()) for b in batches) == float(z["pixels_checksum"])
+    model = build_from_flat(w, "timm")
+    imps = ref_cpu.ffn_activation_importance(model, batches)
+    for i, t in enumerate(imps):
+        assert torch.equal(t.view(torch.int16), bf16_from_bits(z[f"s1_imp_bf16bits.{i}"]).view(torch.int16))
+    masks, _ = ref_cpu.width_prune_selection([t.to(torch.float32) for t in imps], [1120] * 12, min_remaining=512)
+    assert np.array_equal(np.packbits(np.asarray(masks, dtype=np.uint8), axis=1), z["mask.t1120"])
+    assert all(sum(m) == 1120 for m in masks)
+    # stage-2 selection rule on the reference's own impact vector (auto_2ssp.py:857, K = 5)
+    assert ref_cpu.select_blocks_torch_argsort(torch.from_numpy(z["att_imp"]), 5) == z["s2_selected_k5"].tolist()
+    assert z["att_imp"].shape == (12,) and float(z["top1"]) == 1.0 and sum(len(z[f"labels.{i}"]) for i in range(2)) == 64
