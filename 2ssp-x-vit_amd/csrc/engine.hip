@@ -104,6 +104,9 @@ struct ssp2_engine {
   bf16 *q_cls = nullptr, *o_cls = nullptr, *h_cls = nullptr, *act_cls = nullptr;
   float *slab = nullptr, *norms = nullptr, *logits = nullptr;
 
+  float* stage_f32 = nullptr;   // staging buffer of ssp2_load_tensor (host sources)
+  size_t stage_cap = 0;
+
   // profiling
   int prof_class = -1;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -164,12 +167,18 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
 }
 
 template <int EPI, int SCORE = 0>
+static int launch_gemm_small(ssp2_engine* e, GemmArgs g, int klass);
+template <int EPI, int SCORE = 0>
 static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
   if (g.K % GEMM_BK) return fail(SSP2_EINVAL, "GEMM K=%d not a multiple of %d", g.K, GEMM_BK);
   if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID || EPI == EPI_FC1) {
     static const bool fc1_big = !getenv("SSP2_FC1_SMALL_TILES");
     if (g.M >= kBigTileMinRows && !(EPI == EPI_FC1 && (g.out2 || !fc1_big)) && !getenv("SSP2_NO_BIG_TILES")) return launch_gemm256<EPI, SCORE>(e, g, klass);
   }
+  return launch_gemm_small<EPI, SCORE>(e, g, klass);
+}
+template <int EPI, int SCORE>
+static int launch_gemm_small(ssp2_engine* e, GemmArgs g, int klass) {
   g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
   if (g.tiles_m <= 0 || g.tiles_n <= 0) return fail(SSP2_EINVAL, "empty GEMM");
   static bool attr_done = false;
@@ -347,6 +356,7 @@ int ssp2_destroy(ssp2_handle e) {
   hipStreamSynchronize(e->stream);
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   for (void* p : e->allocs) hipFree(p);
+  if (e->stage_f32) hipFree(e->stage_f32);
   delete e;
   return 0;
 }
@@ -361,57 +371,85 @@ int ssp2_tokens(ssp2_handle e) { return e ? e->tokens : SSP2_EINVAL; }
 long ssp2_rows(ssp2_handle e, int n, int group) { return e ? total_rows(make_rowmap(e->tokens, n, group), n) : SSP2_EINVAL; }
 size_t ssp2_workspace_bytes(ssp2_handle e) { return e ? e->ws_bytes : 0; }
 
-static int upload_matrix(Mat& m, const float* host, size_t numel) {
+// Weight ingest.  The fp32 source (nn.Linear [out,in] as stored) is rounded to bf16 and laid out with the padded
+// leading dimension ON THE DEVICE (convert_pad_bf16_kernel): a host source costs one hipMemcpy of the fp32 bytes into a
+// staging buffer, a device source (a module that already lives on the GPU) costs nothing but the kernel.  Round 1
+// converted on the host in a single-threaded double loop over every weight — seconds for ViT-B/16 inside the caller's
+// prune bracket whenever the host API had to (re)build its engine.
+static int stage_fp32(ssp2_engine* e, const float* src, size_t numel, bool src_on_device, const float** out) {
+  if (src_on_device) { *out = src; return 0; }
+  if (e->stage_cap < numel) {
+    if (e->stage_f32) hipFree(e->stage_f32);
+    e->stage_f32 = nullptr; e->stage_cap = 0;
+    if (hipMalloc((void**)&e->stage_f32, numel * 4) != hipSuccess) return fail(SSP2_ENOMEM, "hipMalloc(%zu) for the weight staging buffer failed", numel * 4);
+    e->stage_cap = numel;
+  }
+  HIPCHK(hipMemcpyAsync(e->stage_f32, src, numel * 4, hipMemcpyHostToDevice, e->stream));
+  *out = e->stage_f32;
+  return 0;
+}
+static int upload_matrix(ssp2_engine* e, Mat& m, const float* src, size_t numel, bool dev) {
   if (numel != (size_t)m.rows * m.cols) return fail(SSP2_EINVAL, "matrix expects %d x %d = %zu values, got %zu", m.rows, m.cols, (size_t)m.rows * m.cols, numel);
-  std::vector<uint16_t> tmp((size_t)m.rows_pad * m.ld, 0);
-  for (int r = 0; r < m.rows; ++r)
-    for (int c = 0; c < m.cols; ++c) tmp[(size_t)r * m.ld + c] = f2bf(host[(size_t)r * m.cols + c]);
-  HIPCHK(hipMemcpy(m.w, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+  const float* d = nullptr;
+  int rc;
+  if ((rc = stage_fp32(e, src, numel, dev, &d))) return rc;
+  const long total = (long)m.rows_pad * (m.ld / 8);
+  hipLaunchKernelGGL(convert_pad_bf16_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, e->stream, d, m.w, m.rows, m.cols, m.rows_pad, m.ld);
+  HIPCHK(hipGetLastError());
+  if (!dev) HIPCHK(hipStreamSynchronize(e->stream));     // the staging buffer is reused by the next tensor; the host source may go away
   m.w_set = true;
   return 0;
 }
-static int upload_bias(Mat& m, const float* host, size_t numel) {
+static int upload_bias(ssp2_engine* e, Mat& m, const float* src, size_t numel, bool dev) {
   if (numel != (size_t)m.rows) return fail(SSP2_EINVAL, "bias expects %d values, got %zu", m.rows, numel);
-  std::vector<float> tmp(m.rows_pad, 0.f);
-  for (int r = 0; r < m.rows; ++r) tmp[r] = bf2f(f2bf(host[r]));   // autocast casts the bias to bf16 too
-  HIPCHK(hipMemcpy(m.b, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+  const float* d = nullptr;
+  int rc;
+  if ((rc = stage_fp32(e, src, numel, dev, &d))) return rc;
+  hipLaunchKernelGGL(round_bias_kernel, dim3((m.rows_pad + 255) / 256), dim3(256), 0, e->stream, d, m.b, m.rows, m.rows_pad);   // autocast casts the bias to bf16 too
+  HIPCHK(hipGetLastError());
+  if (!dev) HIPCHK(hipStreamSynchronize(e->stream));
   m.b_set = true;
   return 0;
 }
-static int upload_f32(float* dst, const float* host, size_t numel, size_t expect, bool* flag) {
+static int upload_f32(ssp2_engine* e, float* dst, const float* src, size_t numel, size_t expect, bool* flag, bool dev) {
   if (numel != expect) return fail(SSP2_EINVAL, "vector expects %zu values, got %zu", expect, numel);
-  HIPCHK(hipMemcpy(dst, host, numel * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(dst, src, numel * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+  if (!dev) HIPCHK(hipStreamSynchronize(e->stream));
   *flag = true;
   return 0;
 }
 
-int ssp2_load_tensor(ssp2_handle e, int kind, int layer, const float* host, size_t numel) {
+static int load_tensor_impl(ssp2_handle e, int kind, int layer, const float* src, size_t numel, bool dev);
+int ssp2_load_tensor(ssp2_handle e, int kind, int layer, const float* host, size_t numel) { return load_tensor_impl(e, kind, layer, host, numel, false); }
+int ssp2_load_tensor_dev(ssp2_handle e, int kind, int layer, const float* dev_ptr, size_t numel) { return load_tensor_impl(e, kind, layer, dev_ptr, numel, true); }
+
+static int load_tensor_impl(ssp2_handle e, int kind, int layer, const float* host, size_t numel, bool dev) {
   if (!e || !host) return fail(SSP2_EINVAL, "null argument");
   const int D = e->d.dim;
   const bool per_layer = kind >= SSP2_T_LN1_G && kind <= SSP2_T_FC2_B;
   if (per_layer && (layer < 0 || layer >= e->d.depth)) return fail(SSP2_EINVAL, "layer %d out of range", layer);
   Layer* L = per_layer ? &e->layers[layer] : nullptr;
   switch (kind) {
-    case SSP2_T_PATCH_W: return upload_matrix(e->patch, host, numel);
-    case SSP2_T_PATCH_B: return upload_bias(e->patch, host, numel);
-    case SSP2_T_CLS: return upload_f32(e->cls, host, numel, D, &e->misc_set[0]);
-    case SSP2_T_POS: return upload_f32(e->pos, host, numel, (size_t)e->tokens * D, &e->misc_set[1]);
-    case SSP2_T_LN1_G: return upload_f32(L->ln1_g, host, numel, D, &L->ln_set[0]);
-    case SSP2_T_LN1_B: return upload_f32(L->ln1_b, host, numel, D, &L->ln_set[1]);
-    case SSP2_T_LN2_G: return upload_f32(L->ln2_g, host, numel, D, &L->ln_set[2]);
-    case SSP2_T_LN2_B: return upload_f32(L->ln2_b, host, numel, D, &L->ln_set[3]);
-    case SSP2_T_QKV_W: return upload_matrix(L->qkv, host, numel);
-    case SSP2_T_QKV_B: return upload_bias(L->qkv, host, numel);
-    case SSP2_T_PROJ_W: return upload_matrix(L->proj, host, numel);
-    case SSP2_T_PROJ_B: return upload_bias(L->proj, host, numel);
-    case SSP2_T_FC1_W: return upload_matrix(L->fc1, host, numel);
-    case SSP2_T_FC1_B: return upload_bias(L->fc1, host, numel);
-    case SSP2_T_FC2_W: return upload_matrix(L->fc2, host, numel);
-    case SSP2_T_FC2_B: return upload_bias(L->fc2, host, numel);
-    case SSP2_T_LNF_G: return upload_f32(e->lnf_g, host, numel, D, &e->misc_set[2]);
-    case SSP2_T_LNF_B: return upload_f32(e->lnf_b, host, numel, D, &e->misc_set[3]);
-    case SSP2_T_HEAD_W: return upload_matrix(e->head, host, numel);
-    case SSP2_T_HEAD_B: return upload_bias(e->head, host, numel);
+    case SSP2_T_PATCH_W: return upload_matrix(e, e->patch, host, numel, dev);
+    case SSP2_T_PATCH_B: return upload_bias(e, e->patch, host, numel, dev);
+    case SSP2_T_CLS: return upload_f32(e, e->cls, host, numel, D, &e->misc_set[0], dev);
+    case SSP2_T_POS: return upload_f32(e, e->pos, host, numel, (size_t)e->tokens * D, &e->misc_set[1], dev);
+    case SSP2_T_LN1_G: return upload_f32(e, L->ln1_g, host, numel, D, &L->ln_set[0], dev);
+    case SSP2_T_LN1_B: return upload_f32(e, L->ln1_b, host, numel, D, &L->ln_set[1], dev);
+    case SSP2_T_LN2_G: return upload_f32(e, L->ln2_g, host, numel, D, &L->ln_set[2], dev);
+    case SSP2_T_LN2_B: return upload_f32(e, L->ln2_b, host, numel, D, &L->ln_set[3], dev);
+    case SSP2_T_QKV_W: return upload_matrix(e, L->qkv, host, numel, dev);
+    case SSP2_T_QKV_B: return upload_bias(e, L->qkv, host, numel, dev);
+    case SSP2_T_PROJ_W: return upload_matrix(e, L->proj, host, numel, dev);
+    case SSP2_T_PROJ_B: return upload_bias(e, L->proj, host, numel, dev);
+    case SSP2_T_FC1_W: return upload_matrix(e, L->fc1, host, numel, dev);
+    case SSP2_T_FC1_B: return upload_bias(e, L->fc1, host, numel, dev);
+    case SSP2_T_FC2_W: return upload_matrix(e, L->fc2, host, numel, dev);
+    case SSP2_T_FC2_B: return upload_bias(e, L->fc2, host, numel, dev);
+    case SSP2_T_LNF_G: return upload_f32(e, e->lnf_g, host, numel, D, &e->misc_set[2], dev);
+    case SSP2_T_LNF_B: return upload_f32(e, e->lnf_b, host, numel, D, &e->misc_set[3], dev);
+    case SSP2_T_HEAD_W: return upload_matrix(e, e->head, host, numel, dev);
+    case SSP2_T_HEAD_B: return upload_bias(e, e->head, host, numel, dev);
     default: return fail(SSP2_EINVAL, "unknown tensor kind %d", kind);
   }
 }
@@ -635,6 +673,41 @@ int ssp2_prune_ffn(ssp2_handle e, int layer, const int32_t* keep, int n_keep) {
 int ssp2_act_l2_accum(void* stream, const void* act, int dtype, int n, int tokens, int d, int ld, int chain, int group,
                       float* norms_ws, float* out, size_t out_stride) {
   return act_l2_impl(stream, act, dtype, n, RowMap{tokens, 0, 0}, d, ld, chain, group, norms_ws, out, out_stride);
+}
+
+// The projection operator on its own (a3's building block): out = epilogue(A x W^T + bias) on caller-owned device
+// buffers, routed to the same two kernels as the forward (persistent 256 x 256 tiles for M >= 4096 rows, 128 x 128
+// otherwise; `kernel` = 1 / 2 forces the small / the large one — both give the same bits).
+int ssp2_linear_bf16(void* hip_stream, int epilogue, const uint16_t* a_dev, int lda, const uint16_t* w_dev, int ldw, const float* bias_dev,
+                     int M, int N, int K, uint16_t* out_dev, int ldo, float* x_dev, int ldx, int kernel) {
+  if (!a_dev || !w_dev || !bias_dev) return fail(SSP2_EINVAL, "null operand");
+  if (M <= 0 || N <= 0 || K <= 0 || (K % GEMM_BK) || (N % 64)) return fail(SSP2_EINVAL, "linear: M=%d N=%d K=%d (K multiple of %d, N multiple of 64)", M, N, K, GEMM_BK);
+  if (lda < K || ldw < K || (lda % 8) || (ldw % 8)) return fail(SSP2_EINVAL, "linear: lda=%d ldw=%d must be >= K and multiples of 8", lda, ldw);
+  if (kernel < 0 || kernel > 2) return fail(SSP2_EINVAL, "kernel selector %d", kernel);
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0; hipDeviceProp_t pr;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  ssp2_engine e;
+  e.stream = (hipStream_t)hip_stream; e.n_cu = n_cu;
+  GemmArgs g{};
+  g.A = (const bf16*)a_dev; g.lda = lda; g.W = (const bf16*)w_dev; g.ldw = ldw; g.bias = bias_dev;
+  g.M = M; g.N = N; g.K = K; g.tiles_n = ceil_to(N, 256) / GEMM_BN;
+  g.out = (bf16*)out_dev; g.ldo = ldo; g.x = x_dev; g.ldx = ldx;
+  const bool big = kernel == 2 || (kernel == 0 && M >= kBigTileMinRows);
+  switch (epilogue) {
+    case SSP2_EPI_BF16:
+      if (!out_dev || ldo < N || (ldo % 8)) return fail(SSP2_EINVAL, "linear: out / ldo");
+      return big ? launch_gemm256<EPI_BF16>(&e, g, -2) : launch_gemm_small<EPI_BF16>(&e, g, -2);
+    case SSP2_EPI_GELU:
+      if (!out_dev || ldo < N || (ldo % 8)) return fail(SSP2_EINVAL, "linear: out / ldo");
+      return big ? launch_gemm256<EPI_FC1, 0>(&e, g, -2) : launch_gemm_small<EPI_FC1, 0>(&e, g, -2);
+    case SSP2_EPI_RESID:
+      if (!x_dev || ldx < N || (ldx % 4)) return fail(SSP2_EINVAL, "linear: x / ldx");
+      return big ? launch_gemm256<EPI_RESID>(&e, g, -2) : launch_gemm_small<EPI_RESID>(&e, g, -2);
+    default: return fail(SSP2_EINVAL, "unknown epilogue %d", epilogue);
+  }
 }
 
 int ssp2_profile_begin(ssp2_handle e, int klass) {

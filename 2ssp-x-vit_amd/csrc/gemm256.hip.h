@@ -538,6 +538,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), xr, voff(a, j), xoff(a, b, j), 0);
+          // ... and two wait states before anything may rewrite the stores' data registers (16-byte store data with an
+          // SGPR offset: hipcc / ROCm 7.2 does not pad this case on gfx950, see above) — an instruction-order-independent
+          // guard, so that a scheduling change in a later compiler cannot bring the corruption back
+          asm volatile("s_nop 1" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           if (p + NXB < 8) {                   // block p + NXB takes the registers of block p (pinned: hipcc would
             __builtin_amdgcn_sched_barrier(0); // hoist these loads to the top and spill their destinations)

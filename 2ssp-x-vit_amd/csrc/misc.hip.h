@@ -250,3 +250,24 @@ __global__ void gather_vector_kernel(const float* __restrict__ src, float* __res
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_pad) dst[i] = i < n ? src[keep[i]] : 0.f;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Weight ingest: fp32 [rows, cols] (nn.Linear [out, in]) -> bf16 [rows_pad, ld], zero padded, RNE (NaN stays NaN) —
+// the cast torch.autocast applies to the weight.  One thread per 8 output columns (16-byte store).
+__global__ void convert_pad_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows, int cols, int rows_pad, int ld) {
+  const int chunks = ld / 8;
+  const long total = (long)rows_pad * chunks;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / chunks), c0 = (int)(i - (long)r * chunks) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)((r < rows && c0 + j < cols) ? src[(size_t)r * cols + c0 + j] : 0.f);
+    *(bf16x8*)(dst + (size_t)r * ld + c0) = v;
+  }
+}
+// bias: rounded to bf16, kept as fp32 (the epilogues add it in fp32 registers), zero padded
+__global__ void round_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int n_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) dst[i] = i < n ? bf16_round(src[i]) : 0.f;
+}

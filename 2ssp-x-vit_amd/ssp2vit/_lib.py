@@ -13,9 +13,12 @@ CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libssp2vit.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 
+ABI_VERSION = 2                                         # SSP2_ABI_VERSION of include/ssp2vit.h
+
 # every symbol include/ssp2vit.h declares
 SYMBOLS = [
     "ssp2_abi_version", "ssp2_last_error", "ssp2_create", "ssp2_destroy", "ssp2_set_stream", "ssp2_load_tensor",
+    "ssp2_load_tensor_dev", "ssp2_linear_bf16",
     "ssp2_embed", "ssp2_layers", "ssp2_head", "ssp2_tail", "ssp2_prune_ffn", "ssp2_drop_attention", "ssp2_d_int", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
     "ssp2_tokens", "ssp2_rows", "ssp2_workspace_bytes", "ssp2_preproc_create", "ssp2_preproc_run", "ssp2_preproc_destroy",
 ]
@@ -82,6 +85,35 @@ def _needs_rebuild() -> bool:
         return f.read().strip() != _source_hash()
 
 
+TOOLS = os.path.join(CSRC, "tools")
+
+
+def build_tool(name: str, defines=(), out: Optional[str] = None) -> str:
+    """Build (or reuse) a micro-benchmark of csrc/tools: <name>.hip -> <out or name>.bin.  Staleness is decided by a
+    content hash of the tool's source, EVERY kernel header of csrc/ (the kernels under test live there) and the
+    defines — never by file times, which do not survive the copy to a GPU box."""
+    import hashlib
+    src = os.path.join(TOOLS, name + ".hip")
+    exe = os.path.join(TOOLS, (out or name) + ".bin")
+    h = hashlib.sha256(_source_hash().encode())
+    for f in sorted(os.listdir(TOOLS)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            with open(os.path.join(TOOLS, f), "rb") as fh:
+                h.update(fh.read())
+    h.update(" ".join(defines).encode())
+    want = h.hexdigest()
+    stamp = exe + ".srchash"
+    if os.path.exists(exe) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return exe
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", *defines, src, "-o", exe],
+                   check=True, cwd=TOOLS, timeout=900)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return exe
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -101,6 +133,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_destroy.argtypes = [vp]
     lib.ssp2_set_stream.argtypes = [vp, vp]
     lib.ssp2_load_tensor.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.c_size_t]
+    lib.ssp2_load_tensor_dev.argtypes = [vp, i32, i32, vp, C.c_size_t]
+    lib.ssp2_linear_bf16.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, i32, i32]
     lib.ssp2_embed.argtypes = [vp, vp, i32, vp, i32]
     lib.ssp2_rows.argtypes = [vp, i32, i32]
     lib.ssp2_rows.restype = C.c_long

@@ -27,12 +27,40 @@ def iter_limited(dataloader: Iterable, limit: Optional[int], progress: bool, des
         yield i, batch
 
 
-DEFAULT_CHUNK_IMAGES = int(os.environ.get("SSP2_CHUNK_IMAGES", "256"))
+# Images per forward.  Stage 1 packs whole dataloader batches (each its own slab), the search cuts the eval stream into
+# forwards of exactly this many images; both defaults are the sizes measured best on ViT-B/16 (DESIGN.md section 4:
+# larger is better, the tile-quantisation tail of a 64-image launch costs more than cache residency buys).
+DEFAULT_CHUNK_IMAGES = int(os.environ.get("SSP2_CHUNK_IMAGES", "512"))
+DEFAULT_EVAL_CHUNK_IMAGES = int(os.environ.get("SSP2_EVAL_CHUNK_IMAGES", "320"))
 MAX_SLABS = 16          # the engine's workspace carries slack for 16 padded slabs per call (csrc/engine.hip rows_cap)
 
 
 def _resolve(engine, min_images: int):
     return engine(min_images) if callable(engine) else engine
+
+
+def workspace_budget_bytes(device=None) -> int:
+    """What the layer-major search may spend on engine workspace + snapshots: SSP2_WORKSPACE_GB, else half of the free
+    HBM (288 GB per MI355X; ViT-B/16 needs 13 GB for 12 x 320 images, ViT-H/14 about 75 GB for 32 x 320)."""
+    gb = os.environ.get("SSP2_WORKSPACE_GB")
+    if gb:
+        return int(float(gb) * (1 << 30))
+    if torch.cuda.is_available():
+        free, _ = torch.cuda.mem_get_info(device)
+        return free // 2
+    return 0
+
+
+def layer_major_images(engine, slots: int, n: int, device=None) -> int:
+    """Engine capacity (images) to ask for when `slots` copies of an n-image chunk should run side by side; n when that
+    does not fit the budget or the engine is a fixed object that is too small (the search then runs candidate-major)."""
+    want = slots * n
+    if not callable(engine):
+        return want if engine.max_images >= want else n
+    per_image = getattr(engine, "bytes_per_image", None)
+    if per_image is None:
+        return n
+    return want if want * per_image() <= workspace_budget_bytes(device) else n
 
 
 _COPY_STREAMS = {}
@@ -191,7 +219,7 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
     return imps
 
 
-def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images):
+def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images, capacity=None):
     """Yields (engine, pixels, labels) chunks of EXACTLY `chunk_images` images (the last one may be short) cut from
     the concatenation of the batches this rank owns.  Evaluation results are integer counts, so where the cuts fall
     cannot change them; the chunk size is chosen for the GEMM tile grid (see best_eval_chunk)."""
@@ -211,7 +239,8 @@ def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images):
             continue
         px, labels = batch["pixel_values"], batch["labels"]
         if eng is None:
-            eng = _resolve(engine, max(chunk_images, int(px.size(0))))
+            need = max(chunk_images, int(px.size(0)))
+            eng = _resolve(engine, max(need, capacity(need) if capacity is not None else 0))
         cap = min(eng.max_images, chunk_images) if chunk_images > 0 else min(eng.max_images, int(px.size(0)))
         px_buf.append(_to_device(px, eng.device, torch.float32))
         lb_buf.append(_to_device(labels, eng.device, torch.int64))
@@ -248,7 +277,7 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
     correct_dev = None
     total = 0
     for eng, px, labels in _chunks(engine, dataloader, max_batches, progress, "eval", rank, ws,
-                                   chunk_images or DEFAULT_CHUNK_IMAGES):
+                                   chunk_images or DEFAULT_EVAL_CHUNK_IMAGES):
         if correct_dev is None:
             correct_dev = torch.zeros(1, dtype=torch.int64, device=eng.device)
         n = int(px.size(0))
@@ -270,7 +299,7 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
 def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional[int] = 5, process_group=None,
                         removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None,
                         chunk_images: Optional[int] = None, defer: bool = False, aux_engine=None, aux_stream=None,
-                        aux_lead: float = 0.0, batch_candidates: bool = False):
+                        aux_lead: float = 0.0, batch_candidates="auto"):
     """One pass over the eval batches that yields the baseline AND every candidate's correct-count.
 
     The reference deep-copies the model and re-runs the whole forward per candidate (mask_conjunction.py:339-355,
@@ -285,38 +314,52 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
     of the candidates once the baseline has produced their snapshots — candidates are independent, and two streams
     let the memory-bound kernels of one (LayerNorm, epilogue tails) run beside the matrix-bound kernels of the other.
     `aux_lead` = work already queued on that stream, in block passes of this chunk size (bench: the stage-1 launch);
-    the split balances (baseline + main candidates) against (lead + aux candidates).  Integer counts: same result."""
+    the split balances (baseline + main candidates) against (lead + aux candidates).  Integer counts: same result.
+
+    `batch_candidates`: "auto" (default) runs the LAYER-MAJOR order below whenever the engine's workspace can hold the
+    baseline and all candidates side by side (an engine factory is asked for that capacity if it fits the budget of
+    `workspace_budget_bytes`), True requires it when the engine allows, False keeps the candidate-major order."""
     rank, ws = _dist.world(process_group)
     L = depth
     counts_dev = None
     total = 0
     removed = sorted(set(int(r) for r in removed))
     cands = list(range(L)) if candidates is None else [int(c) for c in candidates]
-    for eng, px, labels in _chunks(engine, dataloader, batch_limit, False, "attn search", rank, ws,
-                                   chunk_images or DEFAULT_CHUNK_IMAGES):
+    cand_set, removed_set = set(cands), set(removed)
+    chunk = chunk_images or DEFAULT_EVAL_CHUNK_IMAGES
+    slots = 1 + sum(1 for c in cand_set if c < L - 1)         # the baseline + every candidate that starts before the tail
+    want_lm = (batch_candidates is True or batch_candidates == "auto") and aux_engine is None and slots > 1
+    cap_fn = (lambda need: layer_major_images(engine, slots, need)) if want_lm else None
+    for eng, px, labels in _chunks(engine, dataloader, batch_limit, False, "attn search", rank, ws, chunk, cap_fn):
         if counts_dev is None:
             counts_dev = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
         n = int(px.size(0))
         x = eng.embed(px)
-        if (batch_candidates and not removed and cands == list(range(L)) and aux_engine is None
-                and eng.max_images >= L * n):
-            # Layer-major search: the baseline (slot 0) and the snapshots (candidate c in slot c + 1) sit side by side
-            # in one buffer, and at block l the baseline and every candidate already under way (c < l) run the block
-            # in ONE launch of (l + 1)*n images — same per-image arithmetic in the same order, l + 2 launches per block
-            # become 2, and the persistent GEMMs lose their partial last round ((l+1)*246.25 row panels instead of
-            # 246.25).  Candidate l itself runs block l alone (its attention is bypassed).  Needs an engine workspace
-            # for L*n images.
+        if want_lm and eng.max_images >= slots * n:
+            # Layer-major search: the baseline (slot 0) and the snapshots (the k-th candidate to start in slot k) sit
+            # side by side in one buffer, and at block l the baseline and every candidate already under way (c < l) run
+            # the block in ONE launch of (k + 1)*n images — same per-image arithmetic in the same order, l + 2 launches
+            # per block become 2, and the persistent GEMMs lose their partial last round ((l+1)*246.25 row panels
+            # instead of 246.25).  Candidate l itself runs block l alone (its attention is bypassed).  Blocks in
+            # `removed` (earlier rounds of the iterative search) are bypassed for every slot alike.  Needs an engine
+            # workspace for slots*n images.
             rows = x.shape[0]
-            xb = torch.empty(L * rows, x.shape[1], dtype=x.dtype, device=x.device)
+            xb = torch.empty(slots * rows, x.shape[1], dtype=x.dtype, device=x.device)
             xb[:rows].copy_(x)
+            started = []
             for l in range(L - 1):
-                xb[(l + 1) * rows:(l + 2) * rows].copy_(xb[:rows])                 # snapshot: input of block l
-                eng.layers(xb[:(l + 1) * rows], (l + 1) * n, l, l + 1)             # baseline + candidates 0..l-1
-                eng.layers(xb[(l + 1) * rows:(l + 2) * rows], n, l, l + 1, [l])    # candidate l: no attention in block l
-            eng.tail(xb[:rows], n, None, labels=labels, correct=counts_dev[L:L + 1])
-            for c in range(L - 1):
-                eng.tail(xb[(c + 1) * rows:(c + 2) * rows], n, None, labels=labels, correct=counts_dev[c:c + 1])
-            eng.tail(xb[:rows], n, [L - 1], labels=labels, correct=counts_dev[L - 1:L])
+                k = len(started)
+                if l in cand_set:
+                    xb[(k + 1) * rows:(k + 2) * rows].copy_(xb[:rows])              # snapshot: input of block l
+                eng.layers(xb[:(k + 1) * rows], (k + 1) * n, l, l + 1, [l] if l in removed_set else None)
+                if l in cand_set:
+                    eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l])   # candidate l: no attention in block l
+                    started.append(l)
+            eng.tail(xb[:rows], n, removed, labels=labels, correct=counts_dev[L:L + 1])
+            for k, c in enumerate(started):
+                eng.tail(xb[(k + 1) * rows:(k + 2) * rows], n, removed, labels=labels, correct=counts_dev[c:c + 1])
+            if (L - 1) in cand_set:
+                eng.tail(xb[:rows], n, removed + [L - 1], labels=labels, correct=counts_dev[L - 1:L])
             total += n
             continue
         cache = {}

@@ -46,16 +46,30 @@ class VitEngine:
 
     # ------------------------------------------------------------------ weights
     def _load(self, w: Dict) -> None:
+        """fp32 tensors in nn.Linear layout -> the engine's bf16 / padded weight image.  The rounding and the padding run
+        in a kernel; a tensor that already lives on this GPU (a module moved to the device, as the reference keeps it)
+        is read in place, a host tensor costs one copy of its fp32 bytes."""
+        self._bind_stream()
+        keep = []
+
         def put(kind: str, layer: int, t: torch.Tensor):
-            t = t.detach().to("cpu", torch.float32).contiguous()
-            check(self.lib.ssp2_load_tensor(self.h, T_KINDS.index(kind), layer,
-                                            C.cast(t.data_ptr(), C.POINTER(C.c_float)), t.numel()))
+            t = t.detach()
+            if t.device == self.device:
+                t = t.to(torch.float32).contiguous()
+                keep.append(t)                                   # alive until the stream has consumed it
+                check(self.lib.ssp2_load_tensor_dev(self.h, T_KINDS.index(kind), layer, C.c_void_p(t.data_ptr()), t.numel()))
+            else:
+                t = t.to("cpu", torch.float32).contiguous()
+                check(self.lib.ssp2_load_tensor(self.h, T_KINDS.index(kind), layer,
+                                                C.cast(t.data_ptr(), C.POINTER(C.c_float)), t.numel()))
         for k in ("patch_w", "patch_b", "cls", "pos", "lnf_g", "lnf_b", "head_w", "head_b"):
             put(k, 0, w[k])
         for i in range(self.depth):
             for k in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_g", "ln2_b",
                       "fc1_w", "fc1_b", "fc2_w", "fc2_b"):
                 put(k, i, w[f"{k}.{i}"])
+        if keep:
+            torch.cuda.current_stream(self.device).synchronize()
 
     def close(self) -> None:
         if getattr(self, "h", None):
@@ -177,6 +191,29 @@ class VitEngine:
         check(self.lib.ssp2_act_l2_accum(C.c_void_p(torch.cuda.current_stream(act.device).cuda_stream), _ptr(act), dtype,
                                          n, t, d, d, SCORE_CHAIN[score_chain], 0, _ptr(ws), _ptr(out), d))
         return out
+
+    def linear(self, a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], epilogue: str = "bf16",
+               x: Optional[torch.Tensor] = None, kernel: str = "auto") -> torch.Tensor:
+        """One projection of the forward on its own (ssp2_linear_bf16): a bf16 [M, K], weight [N, K] (any float dtype,
+        rounded to bf16 like autocast does), bias [N] or None.  epilogue "bf16" / "gelu" -> bf16 [M, N];
+        "resid" -> x (f32 [M, N]) updated in place and returned."""
+        epi = {"bf16": 0, "resid": 1, "gelu": 2}[epilogue]
+        M, K = a.shape
+        N = weight.shape[0]
+        npad = (N + 255) // 256 * 256
+        wp = torch.zeros(npad, K, dtype=torch.bfloat16, device=self.device)
+        wp[:N].copy_(weight.to(self.device, torch.bfloat16))
+        bp = torch.zeros(npad, dtype=torch.float32, device=self.device)
+        if bias is not None:
+            bp[:N].copy_(bias.to(self.device, torch.bfloat16).float())
+        a = a.to(self.device, torch.bfloat16).contiguous()
+        out = None if epi == 1 else torch.empty(M, N, dtype=torch.bfloat16, device=self.device)
+        if epi == 1 and (x is None or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[1] != N or x.shape[0] < M):
+            raise ValueError("resid epilogue needs a contiguous f32 x [>= M, N]")
+        check(self.lib.ssp2_linear_bf16(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), epi, _ptr(a), K,
+                                        _ptr(wp), K, _ptr(bp), M, N, K, _ptr(out), N, _ptr(x if epi == 1 else None), N,
+                                        {"auto": 0, "small": 1, "big": 2}[kernel]))
+        return x if epi == 1 else out
 
     # ------------------------------------------------------------------ compositions used by the host API
     def forward_scores(self, pixels: torch.Tensor, score_site: str, score_chain: str = "fp32",

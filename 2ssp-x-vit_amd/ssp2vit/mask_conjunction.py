@@ -53,33 +53,60 @@ class Auto2SSPInterface(PruningInterface):
     def _num_blocks(self) -> int:
         return len(_vp._blocks(self.nn)[0])
 
-    def _compute_mlp_importance(self) -> List[torch.Tensor]:
+    def _mlp_importance_deferred(self):
+        """All device work enqueued; the returned callable waits and hands back the CPU tensors."""
         if self.dl is not None:
-            imps = _vp._compute_ffn_activation_importance(self.nn, self.dl, device=self.device,
-                                                          batch_limit=self.batch_limit, progress=False,
-                                                          score_chain=self.score_chain,
-                                                          process_group=self.process_group)
-            return [t.detach().to("cpu") for t in imps]
-        return [fc1.weight.abs().sum(dim=1).detach().to("cpu") for fc1, _ in _vp._gather_mlp_pairs(self.nn)]
+            fin = _vp._compute_ffn_activation_importance(self.nn, self.dl, device=self.device,
+                                                         batch_limit=self.batch_limit, progress=False,
+                                                         score_chain=self.score_chain,
+                                                         process_group=self.process_group,
+                                                         defer=(self.score_chain == "fp32"))
+            if callable(fin):
+                return lambda: [t.detach().to("cpu") for t in fin()]
+            return lambda: [t.detach().to("cpu") for t in fin]
+        imps = [fc1.weight.abs().sum(dim=1).detach().to("cpu") for fc1, _ in _vp._gather_mlp_pairs(self.nn)]
+        return lambda: imps
+
+    def _compute_mlp_importance(self) -> List[torch.Tensor]:
+        return self._mlp_importance_deferred()()
 
     def _heuristic(self) -> torch.Tensor:
         B = self._num_blocks()
         return torch.tensor([(i if i < B / 2 else B - i) for i in range(B)], dtype=torch.float32)
 
-    def _compute_att_depth_importance(self) -> torch.Tensor:
+    def _att_importance_deferred(self):
         if self.importance_mode.lower() == "heuristic" or self.dl is None:
-            return self._heuristic()
+            h = self._heuristic()
+            return lambda: h
         try:
-            base, cand, total = _vp.depth_search_counts(self.nn, self.dl, self.device, self.batch_limit,
-                                                        process_group=self.process_group)
+            fin = _vp.depth_search_counts(self.nn, self.dl, self.device, self.batch_limit,
+                                          process_group=self.process_group, defer=True)
         except Exception:
             if getattr(self, "error_policy", "raise") == "raise":
                 raise
-            return self._heuristic()
-        baseline = float(base / max(1, total))
-        return torch.tensor([max(0.0, baseline - float(c / max(1, total))) for c in cand], dtype=torch.float32)
+            h = self._heuristic()
+            return lambda: h
+
+        def finish():
+            try:
+                base, cand, total = fin()
+            except Exception:
+                if getattr(self, "error_policy", "raise") == "raise":
+                    raise
+                return self._heuristic()
+            baseline = float(base / max(1, total))
+            return torch.tensor([max(0.0, baseline - float(c / max(1, total))) for c in cand], dtype=torch.float32)
+        return finish
+
+    def _compute_att_depth_importance(self) -> torch.Tensor:
+        return self._att_importance_deferred()()
 
     def fit(self):
-        self.att_importance = self._compute_att_depth_importance()
-        self.mlp_importance = self._compute_mlp_importance()
+        """Attention first, then MLP, as the reference orders them (:359-362) — but both stages are ENQUEUED before the
+        host waits for either: the two are independent (stage 2 evaluates the dense model), so the GPU never idles
+        between them and the engine (built once, with the layer-major search's workspace) serves both."""
+        att = self._att_importance_deferred()
+        mlp = self._mlp_importance_deferred()
+        self.att_importance = att()
+        self.mlp_importance = mlp()
         return self.att_importance, self.mlp_importance

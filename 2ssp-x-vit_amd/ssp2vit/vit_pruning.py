@@ -135,17 +135,48 @@ def release_engines() -> None:
     _ENGINES.clear()
 
 
+def _tokens_of(model) -> int:
+    for path in ("pos_embed", "vit.embeddings.position_embeddings", "embeddings.position_embeddings"):
+        obj = model
+        try:
+            for name in path.split("."):
+                obj = getattr(obj, name)
+            return int(obj.shape[1])
+        except AttributeError:
+            continue
+    return 197
+
+
+class _EngineFactory:
+    """callable(min_images) -> VitEngine for `model` (cached per model, rebuilt when its weights change), plus the
+    workspace price of one image, which lets core.depth_search_counts decide whether the layer-major search fits."""
+
+    def __init__(self, model, device):
+        self.model, self.device = model, device
+
+    def __call__(self, n: int):
+        return engine_for(self.model, self.device, max_images=n)
+
+    def bytes_per_image(self) -> int:
+        hidden, inters = _get_hidden_and_inter_sizes(self.model)
+        tokens = _tokens_of(self.model)
+        ld_int = (max(inters) + 63) // 64 * 64
+        # csrc/engine.hip ssp2_create: LN output + qkv + attention output + FFN activation (bf16) per token row, the
+        # im2col matrix, and the fp32 residual-stream snapshot the search keeps per slot
+        return tokens * (2 * hidden + 6 * hidden + 2 * hidden + 2 * ld_int) + tokens * 1536 + tokens * hidden * 4
+
+
 def _engine_factory(model, device, engine):
     if engine is not None:
         return engine
-    return lambda n: engine_for(model, device, max_images=n)
+    return _EngineFactory(model, device)
 
 
 # ----------------------------------------------------------------------------- a1/a2 stage-1 scores
 @torch.no_grad()
 def _compute_ffn_activation_importance(vit_model, dataloader, device: str = "cuda", batch_limit: Optional[int] = None,
                                        progress: bool = False, *, score_chain: str = "fp32", process_group=None,
-                                       engine=None) -> List[torch.Tensor]:
+                                       engine=None, defer: bool = False) -> List[torch.Tensor]:
     """Reference :111-201 — mean over calibration samples of the per-sample token-L2 of every block's FFN
     intermediate activation (pre-GELU for timm-layout models, post-GELU for HF-layout ones).
 
@@ -157,7 +188,7 @@ def _compute_ffn_activation_importance(vit_model, dataloader, device: str = "cud
     site = _weights.score_site_for("timm" if kind == "timm" else "hf")
     return _core.stage1_scores(_engine_factory(vit_model, device, engine), dataloader, d_ints, site,
                                batch_limit=batch_limit, progress=progress, score_chain=score_chain,
-                               process_group=process_group)
+                               process_group=process_group, defer=defer)
 
 
 # ----------------------------------------------------------------------------- a7/a8 width prune (host consumer)
@@ -247,11 +278,14 @@ def evaluate_top1(model, dataloader, device: str = "cuda", max_batches: int | No
 # ----------------------------------------------------------------------------- a5 stage-2 search
 @torch.no_grad()
 def depth_search_counts(model, dataloader, device="cuda", batch_limit: Optional[int] = 5, *, process_group=None,
-                        engine=None, removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None):
-    """(baseline_correct, [candidate_correct], total) — see core.depth_search_counts (prefix-cached search)."""
+                        engine=None, removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None,
+                        defer: bool = False, chunk_images: Optional[int] = None, batch_candidates="auto"):
+    """(baseline_correct, [candidate_correct], total) — see core.depth_search_counts (prefix-cached, layer-major
+    whenever the workspace budget allows; `defer=True` returns a callable that waits for the device)."""
     return _core.depth_search_counts(_engine_factory(model, device, engine), dataloader, len(_blocks(model)[0]),
                                      batch_limit=batch_limit, process_group=process_group, removed=removed,
-                                     candidates=candidates)
+                                     candidates=candidates, defer=defer, chunk_images=chunk_images,
+                                     batch_candidates=batch_candidates)
 
 
 class HFAttentionBypass(nn.Module):

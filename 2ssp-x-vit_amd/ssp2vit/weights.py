@@ -93,12 +93,14 @@ def count_params(w: Dict) -> int:
 
 # ----------------------------------------------------------------------------- anatomy adapters
 def _f32(t) -> torch.Tensor:
-    return t.detach().to("cpu", torch.float32).contiguous()
+    """fp32 view / copy ON THE TENSOR'S OWN DEVICE: the engine reads device-resident weights in place
+    (ssp2_load_tensor_dev), so a module that lives on the GPU never round-trips through the host."""
+    return t.detach().to(torch.float32).contiguous()
 
 
 def _bias_or_zeros(lin) -> torch.Tensor:
     """nn.Linear bias, or zeros when the layer was built with bias=False (timm's qkv_bias=False)."""
-    return _f32(lin.bias) if getattr(lin, "bias", None) is not None else torch.zeros(lin.weight.shape[0])
+    return _f32(lin.bias) if getattr(lin, "bias", None) is not None else torch.zeros(lin.weight.shape[0], device=lin.weight.device)
 
 
 def detect_layout(model) -> str:
@@ -209,8 +211,9 @@ def from_module(model) -> Dict:
                                  "the model has no config.num_attention_heads")
     for i in range(depth):  # bypassed attention: supply zero weights, the engine skips the block anyway
         if w.get(f"attn_absent.{i}"):
-            w[f"qkv_w.{i}"] = torch.zeros(3 * dim, dim); w[f"qkv_b.{i}"] = torch.zeros(3 * dim)
-            w[f"proj_w.{i}"] = torch.zeros(dim, dim); w[f"proj_b.{i}"] = torch.zeros(dim)
+            dv = w["patch_w"].device
+            w[f"qkv_w.{i}"] = torch.zeros(3 * dim, dim, device=dv); w[f"qkv_b.{i}"] = torch.zeros(3 * dim, device=dv)
+            w[f"proj_w.{i}"] = torch.zeros(dim, dim, device=dv); w[f"proj_b.{i}"] = torch.zeros(dim, device=dv)
     w.update(img=side * patch, patch=patch, dim=dim, heads=heads, depth=depth,
              classes=int(w["head_w"].shape[0]), eps=eps, layout=layout)
     return w

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SSP2_ABI_VERSION 1
+#define SSP2_ABI_VERSION 2
 
 enum {
   SSP2_OK = 0,
@@ -76,6 +76,11 @@ int ssp2_set_stream(ssp2_handle h, void* hip_stream);
  * (RNE) exactly as torch.autocast casts them, biases are rounded to bf16 and kept as fp32 values, LayerNorm
  * parameters / cls / pos stay fp32.  Synchronous. */
 int ssp2_load_tensor(ssp2_handle h, int kind, int layer, const float* host, size_t numel);
+/* The same from fp32 data that already lives in HBM (a module on the GPU, as the reference keeps it:
+ * `model.to(device)`, adaptation-for-Pures-framework/auto_2ssp.py:693): no host copy, the bf16 rounding and the
+ * padding run in a kernel on the handle's stream.  Asynchronous: dev_ptr must stay valid until the stream has passed
+ * this point. */
+int ssp2_load_tensor_dev(ssp2_handle h, int kind, int layer, const float* dev_ptr, size_t numel);
 
 /* Row layout of the token matrix x.  group <= 0 or >= n: images contiguous, ssp2_rows = n*N.  0 < group < n: SLABS of
  * `group` images (one dataloader batch each), every slab padded to a multiple of 256 rows — a sample then sits at the
@@ -131,6 +136,19 @@ int ssp2_d_int(ssp2_handle h, int layer);
  * HBM-bound: n*tokens*d*sizeof(act) bytes read once. */
 int ssp2_act_l2_accum(void* hip_stream, const void* act_dev, int dtype, int n, int tokens, int d, int ld,
                       int score_chain, int group, float* norms_ws_dev, float* out_dev, size_t out_stride);
+
+/* a3's building block on its own — one nn.Linear of the forward with its fused epilogue, on caller-owned device buffers
+ * (what `F.linear` under autocast computes at src/vit_pruning.py:180 inside the third-party model):
+ *   a_dev bf16 [M, lda] (K used), w_dev bf16 [ceil256(N), ldw] (nn.Linear [out,in]; rows past N zero), bias_dev f32
+ *   [ceil256(N)] holding bf16-representable values; K % 64 == 0, N % 64 == 0.
+ *   SSP2_EPI_BF16  out_dev[M, ldo] = bf16(acc + bias)                     QKV projection
+ *   SSP2_EPI_GELU  out_dev[M, ldo] = bf16(gelu_erf(bf16(acc + bias)))     fc1 (+ the activation)
+ *   SSP2_EPI_RESID x_dev[M, ldx] (f32) += float(bf16(acc + bias))         out-proj / fc2 (+ the residual add)
+ * kernel: 0 = the routing of the forward (M >= 4096 rows: persistent 256 x 256 tiles), 1 / 2 force the 128 x 128 /
+ * the 256 x 256 kernel; all give identical bits. */
+enum { SSP2_EPI_BF16 = 0, SSP2_EPI_RESID = 1, SSP2_EPI_GELU = 2 };
+int ssp2_linear_bf16(void* hip_stream, int epilogue, const uint16_t* a_dev, int lda, const uint16_t* w_dev, int ldw,
+                     const float* bias_dev, int M, int N, int K, uint16_t* out_dev, int ldo, float* x_dev, int ldx, int kernel);
 
 /* f4 — input pipeline on the device, the step in front of the path (adaptation-for-Pures-framework/auto_2ssp.py:
  * 290-301): uint8 HWC images -> bicubic resize to out x out (Pillow's 8-bit fixed-point resampler, bit-identical) ->

@@ -46,7 +46,7 @@ def _logit_tol(ref):
 def test_library_is_the_in_tree_hip_build(gpu):
     from ssp2vit import _lib
     lib = _lib.load(build_if_missing=False)
-    assert lib.ssp2_abi_version() == 1
+    assert lib.ssp2_abi_version() == _lib.ABI_VERSION
     assert os.path.realpath(lib._name).startswith(os.path.realpath(_lib.PKG_ROOT))
 
 
@@ -607,15 +607,9 @@ def test_persistent_gemm_edge_shapes_bitwise_vs_small_tile_kernel(gpu):
     """csrc/tools/gemm_bench bit-compares the persistent 256x256 GEMM with the 128x128 kernel (itself checked against
     the oracle above) on random data: K of one / two / three K-tiles, partial row and column tiles, every epilogue
     incl. both scoring variants (output AND slab) and the residual epilogue (nothing written past row M)."""
-    import shutil
     import subprocess
-    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2ssp-x-vit_amd", "csrc", "tools")
-    exe = os.path.join(tools, "gemm_bench.bin")
-    src = os.path.join(tools, "gemm_bench.hip")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
-        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", src, "-o", exe],
-                       check=True, timeout=600)
+    from ssp2vit import _lib
+    exe = _lib.build_tool("gemm_bench")       # rebuilt whenever the tool OR any kernel header differs from the binary's hash
     for shape in ("8192 128 64 10", "8192 128 64 11", "8192 128 64 12", "8200 64 128 11", "9000 192 192 13",
                   "9001 320 192 14", "5000 2304 768 10", "4100 1984 768 13", "6000 768 1984 11", "12608 768 3072 11"):
         out = subprocess.run([exe] + shape.split() + ["2"], capture_output=True, text=True, timeout=120)

@@ -151,7 +151,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ssp2_abi_version() == 1
+    assert lib.ssp2_abi_version() == _lib.ABI_VERSION
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
