@@ -368,6 +368,19 @@ int ssp2_set_stream(ssp2_handle e, void* s) {
 }
 
 int ssp2_tokens(ssp2_handle e) { return e ? e->tokens : SSP2_EINVAL; }
+int ssp2_query(ssp2_handle e, int what) {
+  if (!e) return SSP2_EINVAL;
+  switch (what) {
+    case SSP2_Q_DIM: return e->d.dim;
+    case SSP2_Q_DEPTH: return e->d.depth;
+    case SSP2_Q_CLASSES: return e->d.classes;
+    case SSP2_Q_SCORE_LD: { int m = 0; for (auto& L : e->layers) m = std::max(m, L.ld_int); return m; }
+    case SSP2_Q_MAX_IMAGES: return e->d.max_images;
+    case SSP2_Q_TOKENS: return e->tokens;
+    case SSP2_Q_IMG: return e->d.img;
+    default: return fail(SSP2_EINVAL, "unknown query %d", what);
+  }
+}
 long ssp2_rows(ssp2_handle e, int n, int group) { return e ? total_rows(make_rowmap(e->tokens, n, group), n) : SSP2_EINVAL; }
 size_t ssp2_workspace_bytes(ssp2_handle e) { return e ? e->ws_bytes : 0; }
 

@@ -1,0 +1,100 @@
+// torch.ops.ssp2vit.* — the PyTorch-ROCm custom-op face of libssp2vit (BASELINE north_star):
+// a thin TORCH_LIBRARY shim over the C ABI of include/ssp2vit.h.  No kernels here and no arithmetic: tensors in,
+// device pointers + the current HIP stream down to the C entry points, freshly allocated tensors out.  Host C++ only
+// (g++); built by __graft_entry__.build() into 2ssp-x-vit_amd/lib/libssp2vit_torch.so next to libssp2vit.so.
+//
+//   forward(handle, pixels[n,3,H,W] f32, attn_skip int[], score_site, score_chain, score_group) -> (logits[n,C] f32, scores[g,L,ld] f32)
+//       = model(px) at reference src/vit_pruning.py:180 / :354 plus the hook body :143-158 when score_site != 0
+//   act_l2_accum(act[n,N,d] bf16|f32, score_chain) -> f32[d]                       the hook body :151-152 on its own
+//   top1_count(handle, pixels, labels[n] i64, attn_skip int[]) -> i64[1]           evaluate_top1's inner loop :353-371
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ssp2vit.h"
+
+namespace {
+
+void check(int rc, const char* what) {
+  if (rc != 0) throw std::runtime_error(std::string("libssp2vit ") + what + ": " + ssp2_last_error());
+}
+void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+ssp2_handle handle_of(int64_t h) {
+  if (!h) throw std::runtime_error("ssp2vit: null engine handle");
+  return reinterpret_cast<ssp2_handle>(static_cast<intptr_t>(h));
+}
+std::vector<uint8_t> skip_flags(ssp2_handle e, at::IntArrayRef attn_skip) {
+  const int depth = ssp2_query(e, SSP2_Q_DEPTH);
+  std::vector<uint8_t> f(depth, 0);
+  for (int64_t i : attn_skip) {
+    if (i < 0 || i >= depth) throw std::runtime_error("ssp2vit: attn_skip index out of range");
+    f[i] = 1;
+  }
+  return f;
+}
+at::Tensor device_pixels(const at::Tensor& pixels, ssp2_handle e) {
+  const int img = ssp2_query(e, SSP2_Q_IMG);
+  TORCH_CHECK(pixels.is_cuda(), "ssp2vit: pixels must live on the HIP device (there is no CPU path)");
+  TORCH_CHECK(pixels.dim() == 4 && pixels.size(1) == 3 && pixels.size(2) == img && pixels.size(3) == img, "ssp2vit: pixels must be [n,3,", img, ",", img, "]");
+  return pixels.to(at::kFloat).contiguous();
+}
+
+std::tuple<at::Tensor, at::Tensor> forward(int64_t handle, const at::Tensor& pixels, at::IntArrayRef attn_skip, int64_t score_site,
+                                           int64_t score_chain, int64_t score_group) {
+  ssp2_handle e = handle_of(handle);
+  const at::Tensor px = device_pixels(pixels, e);
+  const int n = (int)px.size(0), dim = ssp2_query(e, SSP2_Q_DIM), depth = ssp2_query(e, SSP2_Q_DEPTH), classes = ssp2_query(e, SSP2_Q_CLASSES),
+            ld = ssp2_query(e, SSP2_Q_SCORE_LD);
+  const int group = (score_group <= 0 || score_group >= n) ? 0 : (int)score_group;
+  const auto f32 = px.options();
+  at::Tensor x = at::empty({ssp2_rows(e, n, group), dim}, f32);
+  at::Tensor logits = at::empty({n, classes}, f32);
+  const int groups = group ? (n + group - 1) / group : 1;
+  at::Tensor scores = score_site ? at::zeros({groups, depth, ld}, f32) : at::empty({0}, f32);
+  const auto flags = skip_flags(e, attn_skip);
+  check(ssp2_set_stream(e, stream_of(px)), "set_stream");
+  check(ssp2_embed(e, px.data_ptr<float>(), n, x.data_ptr<float>(), group), "embed");
+  check(ssp2_layers(e, x.data_ptr<float>(), n, 0, depth, flags.data(), (int)score_site, (int)score_chain, group,
+                    score_site ? scores.data_ptr<float>() : nullptr, ld), "layers");
+  check(ssp2_head(e, x.data_ptr<float>(), n, group, logits.data_ptr<float>(), nullptr, nullptr, nullptr), "head");
+  return {logits, scores};
+}
+
+at::Tensor act_l2_accum(const at::Tensor& act, int64_t score_chain) {
+  TORCH_CHECK(act.is_cuda() && act.dim() == 3 && act.is_contiguous(), "ssp2vit: act must be a contiguous [n, tokens, d] device tensor");
+  TORCH_CHECK(act.scalar_type() == at::kBFloat16 || act.scalar_type() == at::kFloat, "ssp2vit: act must be bf16 or f32");
+  const int n = (int)act.size(0), t = (int)act.size(1), d = (int)act.size(2);
+  at::Tensor ws = at::empty({n, d}, act.options().dtype(at::kFloat));
+  at::Tensor out = at::empty({d}, act.options().dtype(at::kFloat));
+  check(ssp2_act_l2_accum(stream_of(act), act.data_ptr(), act.scalar_type() == at::kFloat ? 1 : 0, n, t, d, d, (int)score_chain, 0,
+                          ws.data_ptr<float>(), out.data_ptr<float>(), (size_t)d), "act_l2_accum");
+  return out;
+}
+
+at::Tensor top1_count(int64_t handle, const at::Tensor& pixels, const at::Tensor& labels, at::IntArrayRef attn_skip) {
+  ssp2_handle e = handle_of(handle);
+  const at::Tensor px = device_pixels(pixels, e);
+  const int n = (int)px.size(0), dim = ssp2_query(e, SSP2_Q_DIM), depth = ssp2_query(e, SSP2_Q_DEPTH);
+  TORCH_CHECK(labels.numel() == n, "ssp2vit: one label per image");
+  const at::Tensor lb = labels.to(px.device(), at::kLong).contiguous();
+  at::Tensor x = at::empty({ssp2_rows(e, n, 0), dim}, px.options());
+  at::Tensor correct = at::zeros({1}, lb.options());
+  const auto flags = skip_flags(e, attn_skip);
+  check(ssp2_set_stream(e, stream_of(px)), "set_stream");
+  check(ssp2_embed(e, px.data_ptr<float>(), n, x.data_ptr<float>(), 0), "embed");
+  check(ssp2_layers(e, x.data_ptr<float>(), n, 0, depth - 1, flags.data(), 0, 0, 0, nullptr, 0), "layers");
+  check(ssp2_tail(e, x.data_ptr<float>(), n, flags[depth - 1], nullptr, nullptr, lb.data_ptr<int64_t>(), correct.data_ptr<int64_t>()), "tail");
+  return correct;
+}
+
+}  // namespace
+
+TORCH_LIBRARY(ssp2vit, m) {
+  m.def("forward(int handle, Tensor pixels, int[] attn_skip, int score_site, int score_chain, int score_group) -> (Tensor, Tensor)", &forward);
+  m.def("act_l2_accum(Tensor act, int score_chain) -> Tensor", &act_l2_accum);
+  m.def("top1_count(int handle, Tensor pixels, Tensor labels, int[] attn_skip) -> Tensor", &top1_count);
+}

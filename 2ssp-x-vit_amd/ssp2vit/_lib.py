@@ -18,7 +18,7 @@ ABI_VERSION = 2                                         # SSP2_ABI_VERSION of in
 # every symbol include/ssp2vit.h declares
 SYMBOLS = [
     "ssp2_abi_version", "ssp2_last_error", "ssp2_create", "ssp2_destroy", "ssp2_set_stream", "ssp2_load_tensor",
-    "ssp2_load_tensor_dev", "ssp2_linear_bf16",
+    "ssp2_load_tensor_dev", "ssp2_linear_bf16", "ssp2_query",
     "ssp2_embed", "ssp2_layers", "ssp2_head", "ssp2_tail", "ssp2_prune_ffn", "ssp2_drop_attention", "ssp2_d_int", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
     "ssp2_tokens", "ssp2_rows", "ssp2_workspace_bytes", "ssp2_preproc_create", "ssp2_preproc_run", "ssp2_preproc_destroy",
 ]
@@ -85,6 +85,56 @@ def _needs_rebuild() -> bool:
         return f.read().strip() != _source_hash()
 
 
+TORCH_OPS_PATH = os.path.join(PKG_ROOT, "lib", "libssp2vit_torch.so")
+
+
+def build_torch_ops(verbose: bool = False) -> str:
+    """g++ build of csrc/torch_ops.cpp (TORCH_LIBRARY shim, host code only) -> lib/libssp2vit_torch.so, linked against
+    libssp2vit.so (rpath $ORIGIN) and the installed torch.  Rebuilt when its source, the C header or torch changes."""
+    import hashlib
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    h = hashlib.sha256()
+    for f in (src, os.path.join(INCLUDE, "ssp2vit.h")):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(torch.__version__.encode())
+    want = h.hexdigest()
+    stamp = TORCH_OPS_PATH + ".srchash"
+    if os.path.exists(TORCH_OPS_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return TORCH_OPS_PATH
+    if _needs_rebuild():
+        build_library(only_if_stale=True)
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           *[f"-I{p}" for p in ce.include_paths()], "-I/opt/rocm/include", src, "-o", TORCH_OPS_PATH + f".tmp{os.getpid()}",
+           f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", f"-L{os.path.dirname(LIB_PATH)}", "-lssp2vit",
+           "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(cmd[cmd.index("-o") + 1], TORCH_OPS_PATH)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return TORCH_OPS_PATH
+
+
+_ops_loaded = False
+
+
+def load_torch_ops():
+    """Registers torch.ops.ssp2vit.{forward, act_l2_accum, top1_count} (builds the shim if it is missing or stale)."""
+    global _ops_loaded
+    import torch
+    if not _ops_loaded:
+        load()                                           # libssp2vit.so first: the shim links against it
+        torch.ops.load_library(build_torch_ops())
+        _ops_loaded = True
+    return torch.ops.ssp2vit
+
+
 TOOLS = os.path.join(CSRC, "tools")
 
 
@@ -148,6 +198,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_profile_begin.argtypes = [vp, i32]
     lib.ssp2_profile_end.argtypes = [vp, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double)]
     lib.ssp2_tokens.argtypes = [vp]
+    lib.ssp2_query.argtypes = [vp, i32]
     lib.ssp2_workspace_bytes.argtypes = [vp]
     lib.ssp2_workspace_bytes.restype = C.c_size_t
     lib.ssp2_preproc_create.argtypes = [i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(vp)]

@@ -87,6 +87,34 @@ def _to_device(t: torch.Tensor, device, dtype) -> torch.Tensor:
     return out
 
 
+def _pixels_to_device(batch, device) -> torch.Tensor:
+    """`pixel_values` of a dataloader batch -> fp32 NCHW on the device.
+    fp32 batches (what the reference's loaders yield after their torchvision chain) go through `_to_device`.
+    uint8 HWC batches — the raw images, for a loader that leaves the transform to the GPU — carry their
+    `ssp2vit.preprocess.GpuPreprocessor` under batch["preprocess"] (and optional per-image flips under "hflip"): the
+    3-byte pixels cross PCIe on the copy stream (a quarter of the fp32 bytes at equal resolution, 1/200 for CIFAR) and
+    the reference's Resize(BICUBIC) -> flip -> ToTensor -> Normalize (auto_2ssp.py:290-301) runs there as
+    ssp2_preproc_run, bit-identical to the Pillow / torchvision chain; the compute stream waits per batch."""
+    px = batch["pixel_values"]
+    if px.dtype != torch.uint8:
+        return _to_device(px, device, torch.float32)
+    pp = batch.get("preprocess") if hasattr(batch, "get") else None
+    if pp is None:
+        raise ValueError("uint8 pixel_values need batch['preprocess'] (an ssp2vit.preprocess.GpuPreprocessor)")
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    cs = _COPY_STREAMS.get(key)
+    if cs is None:
+        cs = _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+    cur = torch.cuda.current_stream(device)
+    cs.wait_stream(cur)                      # (the preprocessor's tables were uploaded on the creating stream)
+    with torch.cuda.stream(cs):
+        out = pp(px, batch.get("hflip"))
+    cur.wait_stream(cs)
+    out.record_stream(cur)
+    return out
+
+
 class _Chunker:
     """Packs consecutive dataloader batches into one device forward of up to `capacity` images.
 
@@ -107,10 +135,10 @@ class _Chunker:
         return (n > g or self.count + n > self.capacity or self.items[-1][1].size(0) < g
                 or len(self.items) >= self.max_batches)
 
-    def add(self, idx, px, labels=None):
-        self.items.append((idx, _to_device(px, self.device, torch.float32),
+    def add(self, idx, batch, labels=None):
+        self.items.append((idx, _pixels_to_device(batch, self.device),
                            None if labels is None else _to_device(labels, self.device, torch.int64)))
-        self.count += int(px.size(0))
+        self.count += int(batch["pixel_values"].size(0))
 
     def take(self):
         items, self.items, self.count = self.items, [], 0
@@ -124,8 +152,13 @@ class _Chunker:
 @torch.no_grad()
 def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch_limit: Optional[int] = None,
                   progress: bool = False, score_chain: str = "fp32", process_group=None,
-                  chunk_images: Optional[int] = None, defer: bool = False):
+                  chunk_images: Optional[int] = None, defer: bool = False, sharded: bool = False):
     """Reference src/vit_pruning.py:111-201.  `engine`: VitEngine or callable(min_images) -> VitEngine.
+
+    Multi-rank: by default every rank walks the SAME dataloader and keeps batch i iff i % P == rank (the others are
+    only counted).  `sharded=True` says the loader already yields ONLY this rank's batches, in order (its k-th batch
+    is global batch k*P + rank — `dist.rank_batch_indices` builds such a batch sampler): non-owned batches are then
+    never decoded or copied, and the global batch / sample counts come from one extra int64 all_reduce.
 
     Several dataloader batches share one forward (`chunk_images`, default SSP2_CHUNK_IMAGES).  A sample's sum of
     squares is folded per 128-row GEMM tile, so its fp32 rounding depends on where the sample sits relative to the
@@ -152,7 +185,8 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
         px = batch["pixel_values"]
         n = int(px.size(0))
         n_samples += n; n_batches += 1
-        if not _dist.owns(i, rank, ws):
+        gi = i * ws + rank if sharded else i                       # global batch index
+        if not sharded and not _dist.owns(i, rank, ws):
             continue
         if eng is None or (callable(engine) and n > eng.max_images):
             if ch is not None and ch.items:
@@ -166,10 +200,13 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
             ch = _Chunker(cap, eng.device, max_batches=MAX_SLABS)
         if ch.full_for(n):
             flush()
-        ch.add(i, px)
+        ch.add(gi, batch)
     if ch is not None and ch.items:
         flush()
 
+    if sharded and (ws > 1 or (_dist.FORCE_COLLECTIVES and _dist._initialised())):
+        tot = torch.tensor([n_batches, n_samples], dtype=torch.int64, device=_dist._default_device(process_group))
+        n_batches, n_samples = (int(v) for v in _dist.all_reduce_counts(tot, process_group).to("cpu"))
     ld = max((int(d) + 63) // 64 * 64 for d in d_ints) if d_ints else 0          # = VitEngine.score_ld
     vecs = _dist.gather_batch_vectors(local, n_batches, process_group,
                                       shape=(local[0][1].shape if local else (len(d_ints), ld)))
@@ -219,7 +256,7 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
     return imps
 
 
-def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images, capacity=None):
+def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images, capacity=None, sharded=False):
     """Yields (engine, pixels, labels) chunks of EXACTLY `chunk_images` images (the last one may be short) cut from
     the concatenation of the batches this rank owns.  Evaluation results are integer counts, so where the cuts fall
     cannot change them; the chunk size is chosen for the GEMM tile grid (see best_eval_chunk)."""
@@ -235,14 +272,14 @@ def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images, c
         return out
 
     for i, batch in iter_limited(dataloader, limit, progress, desc):
-        if not _dist.owns(i, rank, ws):
+        if not sharded and not _dist.owns(i, rank, ws):
             continue
         px, labels = batch["pixel_values"], batch["labels"]
         if eng is None:
             need = max(chunk_images, int(px.size(0)))
             eng = _resolve(engine, max(need, capacity(need) if capacity is not None else 0))
         cap = min(eng.max_images, chunk_images) if chunk_images > 0 else min(eng.max_images, int(px.size(0)))
-        px_buf.append(_to_device(px, eng.device, torch.float32))
+        px_buf.append(_pixels_to_device(batch, eng.device))
         lb_buf.append(_to_device(labels, eng.device, torch.int64))
         count += int(px.size(0))
         while count >= cap:
@@ -271,13 +308,14 @@ def best_eval_chunk(tokens: int, cap: int, n_cu: int = 256, tile_m: int = 256, c
 
 @torch.no_grad()
 def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process_group=None,
-                attn_skip: Optional[Sequence[int]] = None, chunk_images: Optional[int] = None) -> Tuple[int, int]:
+                attn_skip: Optional[Sequence[int]] = None, chunk_images: Optional[int] = None,
+                sharded: bool = False) -> Tuple[int, int]:
     """Reference src/vit_pruning.py:325-373 as integer counts (correct, total)."""
     rank, ws = _dist.world(process_group)
     correct_dev = None
     total = 0
     for eng, px, labels in _chunks(engine, dataloader, max_batches, progress, "eval", rank, ws,
-                                   chunk_images or DEFAULT_EVAL_CHUNK_IMAGES):
+                                   chunk_images or DEFAULT_EVAL_CHUNK_IMAGES, sharded=sharded):
         if correct_dev is None:
             correct_dev = torch.zeros(1, dtype=torch.int64, device=eng.device)
         n = int(px.size(0))
@@ -299,7 +337,7 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
 def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional[int] = 5, process_group=None,
                         removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None,
                         chunk_images: Optional[int] = None, defer: bool = False, aux_engine=None, aux_stream=None,
-                        aux_lead: float = 0.0, batch_candidates="auto"):
+                        aux_lead: float = 0.0, batch_candidates="auto", sharded: bool = False):
     """One pass over the eval batches that yields the baseline AND every candidate's correct-count.
 
     The reference deep-copies the model and re-runs the whole forward per candidate (mask_conjunction.py:339-355,
@@ -330,7 +368,7 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
     slots = 1 + sum(1 for c in cand_set if c < L - 1)         # the baseline + every candidate that starts before the tail
     want_lm = (batch_candidates is True or batch_candidates == "auto") and aux_engine is None and slots > 1
     cap_fn = (lambda need: layer_major_images(engine, slots, need)) if want_lm else None
-    for eng, px, labels in _chunks(engine, dataloader, batch_limit, False, "attn search", rank, ws, chunk, cap_fn):
+    for eng, px, labels in _chunks(engine, dataloader, batch_limit, False, "attn search", rank, ws, chunk, cap_fn, sharded):
         if counts_dev is None:
             counts_dev = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
         n = int(px.size(0))

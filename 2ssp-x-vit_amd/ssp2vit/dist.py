@@ -35,6 +35,49 @@ def owns(batch_index: int, rank: int, world_size: int) -> bool:
     return batch_index % world_size == rank
 
 
+def rank_batch_indices(n_items: int, batch_size: int, rank: int, world_size: int, limit: Optional[int] = None):
+    """Batch sampler of one rank under the round-robin ownership above: the index lists of global batches rank,
+    rank + P, rank + 2P, ... of a dataset of n_items cut into batches of batch_size (the last one may be short).
+    Use as `DataLoader(dataset, batch_sampler=rank_batch_indices(...))` together with `sharded=True` in core.*: a rank
+    then decodes and copies only what it owns (the default mode walks the whole loader on every rank)."""
+    n_batches = (n_items + batch_size - 1) // batch_size
+    if limit is not None:
+        n_batches = min(n_batches, limit)
+    return [list(range(b * batch_size, min(n_items, (b + 1) * batch_size))) for b in range(rank, n_batches, world_size)]
+
+
+# optional timing of the exchange steps (bench.py --config 2): (name, start event, end event) per collective
+TIMING = False
+EVENTS: List[Tuple[str, object, object]] = []
+
+
+class _timed:
+    def __init__(self, name, device):
+        self.on = TIMING and torch.device(device).type == "cuda"
+        self.name = name
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True); self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.b.record()
+            EVENTS.append((self.name, self.a, self.b))
+        return False
+
+
+def collective_ms() -> dict:
+    """Sum of the recorded collectives' device time per name since the last call (synchronises)."""
+    out = {}
+    for name, a, b in EVENTS:
+        b.synchronize()
+        out[name] = out.get(name, 0.0) + a.elapsed_time(b)
+    EVENTS.clear()
+    return out
+
+
 def gather_batch_vectors(local: Sequence[Tuple[int, torch.Tensor]], n_batches_total: int, group=None,
                          shape: Optional[Tuple[int, int]] = None) -> List[torch.Tensor]:
     """local = [(global batch index, tensor [L, ld])] owned by this rank (round-robin ownership).
@@ -62,7 +105,8 @@ def gather_batch_vectors(local: Sequence[Tuple[int, torch.Tensor]], n_batches_to
         assert idx % ws == rank, "batch not owned by this rank"
         mine[idx // ws].copy_(v)
     everyone = [torch.empty_like(mine) for _ in range(ws)]
-    dist.all_gather(everyone, mine, group=group)
+    with _timed("stage1_all_gather", dev):
+        dist.all_gather(everyone, mine, group=group)
     return [everyone[i % ws][i // ws] for i in range(n_batches_total)]
 
 
@@ -71,7 +115,8 @@ def all_reduce_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
     import torch.distributed as dist
     _, ws = world(group)
     if ws > 1 or (FORCE_COLLECTIVES and _initialised()):
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        with _timed("counts_all_reduce", counts.device):
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     return counts
 
 

@@ -176,7 +176,7 @@ def _engine_factory(model, device, engine):
 @torch.no_grad()
 def _compute_ffn_activation_importance(vit_model, dataloader, device: str = "cuda", batch_limit: Optional[int] = None,
                                        progress: bool = False, *, score_chain: str = "fp32", process_group=None,
-                                       engine=None, defer: bool = False) -> List[torch.Tensor]:
+                                       engine=None, defer: bool = False, sharded: bool = False) -> List[torch.Tensor]:
     """Reference :111-201 — mean over calibration samples of the per-sample token-L2 of every block's FFN
     intermediate activation (pre-GELU for timm-layout models, post-GELU for HF-layout ones).
 
@@ -188,7 +188,7 @@ def _compute_ffn_activation_importance(vit_model, dataloader, device: str = "cud
     site = _weights.score_site_for("timm" if kind == "timm" else "hf")
     return _core.stage1_scores(_engine_factory(vit_model, device, engine), dataloader, d_ints, site,
                                batch_limit=batch_limit, progress=progress, score_chain=score_chain,
-                               process_group=process_group, defer=defer)
+                               process_group=process_group, defer=defer, sharded=sharded)
 
 
 # ----------------------------------------------------------------------------- a7/a8 width prune (host consumer)
@@ -261,9 +261,9 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
 # ----------------------------------------------------------------------------- a4 top-1
 @torch.no_grad()
 def _top1_counts(model, dataloader, device="cuda", max_batches=None, progress=False, *, process_group=None,
-                 engine=None, attn_skip: Optional[Sequence[int]] = None) -> Tuple[int, int]:
+                 engine=None, attn_skip: Optional[Sequence[int]] = None, sharded: bool = False) -> Tuple[int, int]:
     return _core.top1_counts(_engine_factory(model, device, engine), dataloader, max_batches=max_batches,
-                             progress=progress, process_group=process_group, attn_skip=attn_skip)
+                             progress=progress, process_group=process_group, attn_skip=attn_skip, sharded=sharded)
 
 
 @torch.no_grad()
@@ -279,13 +279,14 @@ def evaluate_top1(model, dataloader, device: str = "cuda", max_batches: int | No
 @torch.no_grad()
 def depth_search_counts(model, dataloader, device="cuda", batch_limit: Optional[int] = 5, *, process_group=None,
                         engine=None, removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None,
-                        defer: bool = False, chunk_images: Optional[int] = None, batch_candidates="auto"):
+                        defer: bool = False, chunk_images: Optional[int] = None, batch_candidates="auto",
+                        sharded: bool = False):
     """(baseline_correct, [candidate_correct], total) — see core.depth_search_counts (prefix-cached, layer-major
     whenever the workspace budget allows; `defer=True` returns a callable that waits for the device)."""
     return _core.depth_search_counts(_engine_factory(model, device, engine), dataloader, len(_blocks(model)[0]),
                                      batch_limit=batch_limit, process_group=process_group, removed=removed,
                                      candidates=candidates, defer=defer, chunk_images=chunk_images,
-                                     batch_candidates=batch_candidates)
+                                     batch_candidates=batch_candidates, sharded=sharded)
 
 
 class HFAttentionBypass(nn.Module):

@@ -170,6 +170,8 @@ int ssp2_profile_begin(ssp2_handle h, int klass);                       /* start
 int ssp2_profile_end(ssp2_handle h, double* total_ms, int64_t* launches, double* gemm_flops);
 
 /* workspace / capacity queries */
+enum { SSP2_Q_DIM = 0, SSP2_Q_DEPTH, SSP2_Q_CLASSES, SSP2_Q_SCORE_LD /* max ceil64(d_int) */, SSP2_Q_MAX_IMAGES, SSP2_Q_TOKENS, SSP2_Q_IMG };
+int ssp2_query(ssp2_handle h, int what);                                  /* >= 0, or SSP2_EINVAL */
 int ssp2_tokens(ssp2_handle h);
 size_t ssp2_workspace_bytes(ssp2_handle h);
 

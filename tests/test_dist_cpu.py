@@ -89,21 +89,30 @@ def _batches():
     return w, out
 
 
-def _run_all(process_group=None):
+def _run_all(process_group=None, sharded=False):
     from oracle.vit_modules import build_from_flat
-    from ssp2vit import vit_pruning as vp
+    from ssp2vit import dist as D, vit_pruning as vp
     w, batches = _batches()
     model = build_from_flat(w, "timm")
     eng = OracleBackedEngine(model)
-    imps = vp._compute_ffn_activation_importance(model, batches, device="cpu", engine=eng, process_group=process_group)
-    imps3 = vp._compute_ffn_activation_importance(model, batches, device="cpu", batch_limit=3, engine=eng,
-                                                  process_group=process_group)
-    counts = vp.depth_search_counts(model, batches, "cpu", None, engine=eng, process_group=process_group)
-    top1 = vp._top1_counts(model, batches, "cpu", None, engine=eng, process_group=process_group)
+    if sharded:
+        # the loader hands every rank ONLY its own batches (what DataLoader(batch_sampler=D.rank_batch_indices(...)) does):
+        # 19 items in batches of 4 -> the same 5 batches, dealt round-robin
+        rank, ws = D.world(process_group)
+        px_all = torch.cat([b["pixel_values"] for b in batches]); lb_all = torch.cat([b["labels"] for b in batches])
+        mine = D.rank_batch_indices(19, 4, rank, ws)
+        assert [len(ix) for ix in D.rank_batch_indices(19, 4, 0, 1)] == [4, 4, 4, 4, 3]
+        batches = [{"pixel_values": px_all[ix], "labels": lb_all[ix]} for ix in mine]
+    kw = dict(engine=eng, process_group=process_group, sharded=sharded)
+    imps = vp._compute_ffn_activation_importance(model, batches, device="cpu", **kw)
+    lim = 3 if not sharded else None            # a batch limit counts LOCAL batches in sharded mode: not comparable
+    imps3 = vp._compute_ffn_activation_importance(model, batches, device="cpu", batch_limit=lim, **kw)
+    counts = vp.depth_search_counts(model, batches, "cpu", None, **kw)
+    top1 = vp._top1_counts(model, batches, "cpu", None, **kw)
     return imps, imps3, counts, top1
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, sharded=False):
     for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -111,7 +120,7 @@ def _worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        res = _run_all()
+        res = _run_all(sharded=sharded)
         torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -130,6 +139,25 @@ def test_two_rank_gloo_results_equal_single_process(tmp_path):
             assert torch.equal(a, b)
         assert counts == ref[2] and top1 == ref[3]
     assert ref[2][2] == 19 and ref[3][1] == 19                  # every image counted exactly once
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("sharded", [False, True])
+def test_four_rank_gloo_ragged_ownership_equals_single_process(tmp_path, sharded):
+    """world_size 4 over 5 batches (ownership 2 + 1 + 1 + 1, ragged last batch of 3 images on rank 0), in both loader
+    modes: every rank walks the whole loader / every rank is handed only its own batches (sharded=True: the totals
+    come from one more int64 all_reduce).  Scores bit-identical to one rank, every image counted once."""
+    torch.set_num_threads(1)
+    ref = _run_all()
+    mp.spawn(_worker, args=(4, _free_port(), str(tmp_path), sharded), nprocs=4, join=True)
+    for r in range(4):
+        imps, imps3, counts, top1 = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        for a, b in zip(imps, ref[0]):
+            assert torch.equal(a, b)
+        for a, b in zip(imps3, ref[1] if not sharded else ref[0]):
+            assert torch.equal(a, b)
+        assert counts == ref[2] and top1 == ref[3]
+    assert ref[2][2] == 19
 
 
 def test_gather_is_identity_without_process_group():

@@ -303,3 +303,17 @@ def test_transformers5_anatomy_plan_mask_step_and_bypass():
     flat2 = W.from_module(m)
     assert flat2["attn_absent.0"] and flat2["attn_absent.1"] and flat2["heads"] == 4
     assert flat2["fc1_w.2"].shape == (88, 64) and flat2["fc2_w.2"].shape == (64, 88)
+
+
+def test_torch_ops_are_registered_with_the_declared_schemas():
+    """torch.ops.ssp2vit.* exist once the shim is loaded (no compute here: that needs the GPU)."""
+    from ssp2vit import _lib
+    ops = _lib.load_torch_ops()
+    sch = {n: str(getattr(ops, n).default._schema) for n in ("forward", "act_l2_accum", "top1_count")}
+    assert sch["forward"] == ("ssp2vit::forward(int handle, Tensor pixels, int[] attn_skip, int score_site, int score_chain, "
+                              "int score_group) -> (Tensor, Tensor)")
+    assert sch["act_l2_accum"] == "ssp2vit::act_l2_accum(Tensor act, int score_chain) -> Tensor"
+    assert sch["top1_count"] == "ssp2vit::top1_count(int handle, Tensor pixels, Tensor labels, int[] attn_skip) -> Tensor"
+    with pytest.raises(RuntimeError):
+        ops.act_l2_accum(torch.zeros(2, 3, 8), 0)                    # CPU tensor: refused, there is no CPU path
+    assert os.path.realpath(_lib.TORCH_OPS_PATH).startswith(os.path.realpath(PKG))
