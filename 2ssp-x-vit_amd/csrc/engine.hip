@@ -78,6 +78,7 @@ struct Layer {
   Mat qkv, proj, fc1, fc2;
   int d_int = 0, ld_int = 0;
   bool attn_dropped = false;   // ssp2_drop_attention: bypass for good
+  int* keep_dev = nullptr;     // ssp2_prune_ffn_into: the kept-neuron list on the device
 };
 
 struct ssp2_engine {
@@ -680,6 +681,67 @@ int ssp2_prune_ffn(ssp2_handle e, int layer, const int32_t* keep, int n_keep) {
   L.d_int = n_keep; L.ld_int = new_ld;
   L.fc1.rows = n_keep; L.fc2.cols = n_keep; L.fc2.ld = new_ld;
   e->d_int[layer] = n_keep;
+  return 0;
+}
+
+int ssp2_restore_attention(ssp2_handle e, int layer) {
+  if (!e || layer < 0 || layer >= e->d.depth) return fail(SSP2_EINVAL, "bad layer");
+  e->layers[layer].attn_dropped = false;
+  return 0;
+}
+
+static int copy_mat(ssp2_engine* dst, Mat& d, const Mat& s) {
+  if (d.rows_pad != s.rows_pad || d.ld != s.ld) return fail(SSP2_EINVAL, "clone: matrix shapes differ (%d x %d vs %d x %d)", d.rows_pad, d.ld, s.rows_pad, s.ld);
+  HIPCHK(hipMemcpyAsync(d.w, s.w, (size_t)d.rows_pad * d.ld * 2, hipMemcpyDeviceToDevice, dst->stream));
+  HIPCHK(hipMemcpyAsync(d.b, s.b, (size_t)d.rows_pad * 4, hipMemcpyDeviceToDevice, dst->stream));
+  d.w_set = s.w_set; d.b_set = s.b_set;
+  return 0;
+}
+
+int ssp2_clone_weights(ssp2_handle dst, ssp2_handle src) {
+  if (!dst || !src) return fail(SSP2_EINVAL, "null handle");
+  const ssp2_vit_desc &a = dst->d, &b = src->d;
+  if (a.img != b.img || a.patch != b.patch || a.dim != b.dim || a.heads != b.heads || a.depth != b.depth || a.classes != b.classes)
+    return fail(SSP2_EINVAL, "clone: the two engines describe different architectures");
+  const int D = a.dim;
+  int rc;
+  auto cp = [&](float* d, const float* s, size_t n) -> int { HIPCHK(hipMemcpyAsync(d, s, n * 4, hipMemcpyDeviceToDevice, dst->stream)); return 0; };
+  if ((rc = copy_mat(dst, dst->patch, src->patch)) || (rc = copy_mat(dst, dst->head, src->head))) return rc;
+  if ((rc = cp(dst->cls, src->cls, D)) || (rc = cp(dst->pos, src->pos, (size_t)dst->tokens * D)) || (rc = cp(dst->lnf_g, src->lnf_g, D)) || (rc = cp(dst->lnf_b, src->lnf_b, D))) return rc;
+  for (int i = 0; i < 4; ++i) dst->misc_set[i] = src->misc_set[i];
+  for (int l = 0; l < a.depth; ++l) {
+    Layer &d = dst->layers[l]; const Layer& s = src->layers[l];
+    if ((rc = cp(d.ln1_g, s.ln1_g, D)) || (rc = cp(d.ln1_b, s.ln1_b, D)) || (rc = cp(d.ln2_g, s.ln2_g, D)) || (rc = cp(d.ln2_b, s.ln2_b, D))) return rc;
+    for (int i = 0; i < 4; ++i) d.ln_set[i] = s.ln_set[i];
+    if ((rc = copy_mat(dst, d.qkv, s.qkv)) || (rc = copy_mat(dst, d.proj, s.proj))) return rc;
+    d.attn_dropped = s.attn_dropped;
+    if (d.d_int == s.d_int) { if ((rc = copy_mat(dst, d.fc1, s.fc1)) || (rc = copy_mat(dst, d.fc2, s.fc2))) return rc; }
+    else {   // the FFN arrives through ssp2_prune_ffn_into; fc2's bias does not depend on the kept neurons
+      HIPCHK(hipMemcpyAsync(d.fc2.b, s.fc2.b, (size_t)d.fc2.rows_pad * 4, hipMemcpyDeviceToDevice, dst->stream));
+      d.fc2.b_set = s.fc2.b_set;
+    }
+  }
+  return 0;
+}
+
+int ssp2_prune_ffn_into(ssp2_handle dst, ssp2_handle src, int layer, const int32_t* keep, int n_keep) {
+  if (!dst || !src || !keep || layer < 0 || layer >= src->d.depth || layer >= dst->d.depth) return fail(SSP2_EINVAL, "bad argument");
+  Layer& S = src->layers[layer]; Layer& T = dst->layers[layer];
+  if (dst->d.dim != src->d.dim) return fail(SSP2_EINVAL, "prune_ffn_into: hidden sizes differ");
+  if (n_keep != T.d_int) return fail(SSP2_EINVAL, "prune_ffn_into: destination block %d is %d wide, keep list has %d entries", layer, T.d_int, n_keep);
+  if (n_keep > S.d_int) return fail(SSP2_EINVAL, "n_keep=%d > source d_int=%d", n_keep, S.d_int);
+  for (int i = 0; i < n_keep; ++i)
+    if (keep[i] < 0 || keep[i] >= S.d_int || (i && keep[i] <= keep[i - 1])) return fail(SSP2_EINVAL, "keep list must be ascending and inside [0, d_int)");
+  if (!(S.fc1.w_set && S.fc1.b_set && S.fc2.w_set)) return fail(SSP2_ESTATE, "layer %d MLP weights not loaded", layer);
+  const int D = src->d.dim;
+  if (!T.keep_dev) { HIPCHK(hipMalloc((void**)&T.keep_dev, (size_t)T.ld_int * 4)); dst->allocs.push_back(T.keep_dev); }
+  // (pageable source: the runtime stages the bytes before it returns, the caller's list may go away)
+  HIPCHK(hipMemcpyAsync(T.keep_dev, keep, (size_t)n_keep * 4, hipMemcpyHostToDevice, dst->stream));
+  hipLaunchKernelGGL(gather_matrix_kernel, dim3(2048), dim3(256), 0, dst->stream, S.fc1.w, S.fc1.ld, T.fc1.w, T.fc1.ld, T.fc1.rows_pad, n_keep, D, (const int*)T.keep_dev, (const int*)nullptr);
+  hipLaunchKernelGGL(gather_vector_kernel, dim3((T.fc1.rows_pad + 255) / 256), dim3(256), 0, dst->stream, S.fc1.b, T.fc1.b, T.fc1.rows_pad, n_keep, (const int*)T.keep_dev);
+  hipLaunchKernelGGL(gather_matrix_kernel, dim3(2048), dim3(256), 0, dst->stream, S.fc2.w, S.fc2.ld, T.fc2.w, T.fc2.ld, T.fc2.rows_pad, D, n_keep, (const int*)nullptr, (const int*)T.keep_dev);
+  HIPCHK(hipGetLastError());
+  T.fc1.w_set = T.fc1.b_set = T.fc2.w_set = true;
   return 0;
 }
 

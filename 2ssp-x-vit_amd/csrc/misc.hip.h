@@ -141,7 +141,7 @@ __global__ void score_colsum_kernel(const float* __restrict__ norms, float* __re
 // Standalone activation-L2 kernel (the hook body on an activation tensor resident in HBM) — HBM-bound.
 //   act [n, tokens, ld] (bf16 or f32) ; norms[s][j] = sqrt(sum_t act[s,t,j]^2)
 // grid (ld/512, n); 256 threads: wave w streams tokens w, w+4, ... ; lane owns 8 consecutive neurons
-// (one 16-B load per token row for bf16), 4 token rows in flight per wave; cross-wave fold through LDS.
+// (one 16-B load per token row for bf16), 16 token rows in flight per wave; cross-wave fold through LDS.
 template <typename T>
 __device__ __forceinline__ void load8(const T* p, float (&f)[8]);
 template <>
@@ -172,6 +172,17 @@ __global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__
   if (ok) {
     const T* base = act + (size_t)row_of(rm, s) * ld + col;
     int t = wave;
+    // 16 token rows in flight per wave (16 KiB; ~6 waves per CU => ~96 KiB per CU outstanding): with 4 rows the loop was
+    // latency-bound (13 round trips of ~1.2 us per wave = the whole 16 us of the launch), now 3 round trips + a tail
+    for (; t + 60 < tokens; t += 64) {
+      float f[16][8];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) load8<T>(base + (size_t)(t + 4 * r) * ld, f[r]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 4)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += f[r][k] * f[r][k] + f[r + 1][k] * f[r + 1][k] + f[r + 2][k] * f[r + 2][k] + f[r + 3][k] * f[r + 3][k];
+    }
     for (; t + 12 < tokens; t += 16) {
       float f0[8], f1[8], f2[8], f3[8];
       load8<T>(base + (size_t)t * ld, f0);

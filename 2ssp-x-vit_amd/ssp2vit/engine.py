@@ -17,7 +17,16 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class VitEngine:
-    def __init__(self, weights: Dict, device: str | torch.device = "cuda:0", max_images: int = 64):
+    def __init__(self, weights: Optional[Dict], device: str | torch.device = "cuda:0", max_images: int = 64, *,
+                 precision: str = "bf16", _twin_of: Optional["VitEngine"] = None, _d_int: Optional[Sequence[int]] = None):
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
+        self.precision = precision
+        if _twin_of is not None:          # same architecture, other FFN widths, weights cloned on the device
+            src = _twin_of
+            weights = dict(depth=src.depth, dim=src.dim, classes=src.classes, img=src.img, patch=src.patch, heads=src.heads,
+                           eps=src.eps, **{f"fc1_w.{i}": torch.empty(int(d), 0) for i, d in enumerate(_d_int)})
+            device = src.device
         if not torch.cuda.is_available():
             raise Ssp2Error("ssp2vit needs an MI355X (HIP device): there is no CPU fallback in the product path")
         self.device = torch.device(device)
@@ -30,6 +39,7 @@ class VitEngine:
         self.dim = int(weights["dim"])
         self.classes = int(weights["classes"])
         self.img = int(weights["img"])
+        self.patch, self.heads, self.eps = int(weights["patch"]), int(weights["heads"]), float(weights.get("eps", 1e-6))
         self.d_int = [int(weights[f"fc1_w.{i}"].shape[0]) for i in range(self.depth)]
         self.score_ld = max((d + 63) // 64 * 64 for d in self.d_int)
         self.max_images = int(max_images)
@@ -42,7 +52,12 @@ class VitEngine:
             check(self.lib.ssp2_create(C.byref(desc), C.byref(h)))
             self.h = h
             self.tokens = self.lib.ssp2_tokens(self.h)
-            self._load(weights)
+            if _twin_of is None:
+                self._load(weights)
+            else:
+                self._bind_stream()
+                check(self.lib.ssp2_clone_weights(self.h, _twin_of.h))
+                self.absent = list(_twin_of.absent)
 
     # ------------------------------------------------------------------ weights
     def _load(self, w: Dict) -> None:
@@ -102,6 +117,28 @@ class VitEngine:
         for l in layers:
             check(self.lib.ssp2_drop_attention(self.h, int(l)))
             self.absent[int(l)] = True
+
+    def pruned_twin(self, d_int: Sequence[int], max_images: int = 64) -> "VitEngine":
+        """A second engine of the same architecture with FFN widths `d_int`, every other weight cloned device to
+        device: the container `apply_into` fills.  Built once (outside a timed region); a prune then costs gathers only."""
+        return VitEngine(None, max_images=max_images, _twin_of=self, _d_int=list(d_int))
+
+    def apply_into(self, twin: "VitEngine", masks: Sequence[Sequence[int]], drop_blocks: Sequence[int]) -> "VitEngine":
+        """Stage-1 + stage-2 APPLY (reference src/vit_pruning.py:297-311 and :499-504) into `twin`, leaving this dense
+        engine untouched: kept FFN neurons of every block are gathered in HBM, the chosen blocks lose their attention.
+        Asynchronous on the current stream.  masks[l][j] == 1 -> neuron j of block l is pruned."""
+        twin._bind_stream()
+        for l, m in enumerate(masks):
+            keep = m if isinstance(m, torch.Tensor) else torch.as_tensor(m)
+            keep = torch.nonzero(keep == 0).view(-1).to(torch.int32).contiguous()
+            check(self.lib.ssp2_prune_ffn_into(twin.h, self.h, l, C.cast(keep.data_ptr(), C.POINTER(C.c_int32)), keep.numel()))
+        drop = set(int(b) for b in drop_blocks)
+        for l in range(self.depth):
+            if l in drop or self.absent[l]:
+                check(self.lib.ssp2_drop_attention(twin.h, l)); twin.absent[l] = True
+            else:
+                check(self.lib.ssp2_restore_attention(twin.h, l)); twin.absent[l] = False
+        return twin
 
     # ------------------------------------------------------------------ plumbing
     def _bind_stream(self) -> None:

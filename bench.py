@@ -7,17 +7,26 @@
 One STEP = one full pass of the hot path over one synthetic calibration+eval set resident in HBM:
     stage 1  per-neuron activation-L2 scores over `--calib` images (default 512, batches of 64)
     stage 2  one-shot attention-removal search: baseline + L candidates over `--eval-batches` x 64 images
-    apply    plan (K=5 blocks, t=1120 neurons), mask selection (host argsort on 12x3072 scores), block selection
-This is the reference CLI's "prune time" bracket (importance computation .. stage-2 selection), model/data load
-and post-prune evaluation excluded.  `value` = reference-equivalent image-forwards per second, whole job:
+    select   plan (K=5 blocks, t=1120 neurons), mask step (host argsort on 12x3072 scores), block selection
+    apply    the kept FFN neurons are gathered and the chosen attention blocks dropped INTO A SECOND ENGINE
+             (engine.apply_into: the dense engine stays intact for the next step, as the reference's deep copy does)
+This is the reference CLI's "prune time" bracket (importance computation .. just after stage-2 apply), model /
+data load and post-prune evaluation excluded.  `value` = reference-equivalent image-forwards per second, whole job:
     N_gpus * (calib + (L+1) * eval_images) * K / max-over-ranks(time of K steps)
 (the reference runs L+1 FULL eval passes; the engine's prefix-cached search executes fewer block passes for the
-same result — `executed_block_pass_fraction` says how many).  Multi-GPU is weak scaling: every rank holds its own
-shard of `calib`/`eval` images, weights replicated; the only collectives are one all_gather of per-batch score
-vectors and one all_reduce of int64 counts per step (RCCL).
+same result — `executed_block_pass_fraction` says how many).  Multi-GPU, default: weak scaling, every rank holds its
+own shard of `calib`/`eval` images (its loader yields only its own batches), weights replicated; the only collectives
+are one all_gather of per-batch score vectors and int64 count all_reduces per step (RCCL).
 
-Extra objects on the JSON line: `roofline` (dominant kernel = the fused fc1+GELU+L2 GEMM, HIP events around every
-launch inside the timed region) and `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1).
+`--config 2` = BASELINE.json configs[2]: 2048 calibration + 2560 evaluation images IN TOTAL, dealt to the ranks batch by
+batch (strong scaling), ONE stage-1 pass and ONE search, then plan + masks + selection + apply for each of the targets
+0.25 / 0.375 / 0.5; the line carries the collectives' device time per step.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = the fc1 GEMM family, HIP events around every launch inside
+the timed region; `traffic` / `pmc` only from PMC summaries recorded at THIS source hash), `act_l2_kernel` (the HBM-bound
+standalone hook-body kernel over a rotation of activations larger than the Infinity Cache), `api` (the same prune
+through the reference-named Python API on a live module, engine build included) and `cpu_baseline` (the CPU oracle
+timed on this box's host cores, rank 0, N=1).
 """
 from __future__ import annotations
 
@@ -35,55 +44,47 @@ for p in (ROOT, os.path.join(ROOT, "2ssp-x-vit_amd")):
 import torch  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+FP8_MFMA_PEAK_TFLOPS = 5000.0    # dense, same table ("Peak FP8 MFMA")
+
+
+def _newest_summary(pattern):
+    """Newest committed PMC summary of that kind whose recorded library source hash equals the running library's
+    (counters cannot be read from inside the process; a summary of another kernel revision is not evidence)."""
+    import glob
+    from ssp2vit import _lib
+    want = _lib._source_hash()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            with open(path) as f:
+                js = json.load(f)
+        except Exception:
+            continue
+        if js.get("lib_source_hash") == want:
+            return js, os.path.basename(path), None
+        stale = stale or os.path.basename(path)
+    return None, None, stale
 
 
 def pmc_traffic():
-    """HBM bytes per fc1 launch (launch-weighted over the same launch mix), from the committed rocprofv3 PMC passes
-    (scripts/pmc_traffic.sh -> profiles/r<round>_<tag>_pmc_traffic.json, newest file; counters cannot be read from inside the process)."""
-    import glob
-    try:
-        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
-        with open(newest) as f:
-            return int(json.load(f)["fc1_family"]["avg_hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    js, name, stale = _newest_summary("r*_pmc_traffic.json")
+    if js is None:
+        return None, {"stale_summary_ignored": stale} if stale else None
+    return int(js["fc1_family"]["avg_hbm_bytes_per_launch"]), {"source": name}
 
 
 def pmc_mfma():
-    """Matrix-pipe busy fraction (of the cycles the part actually ran) and shader clock of the fc1 search kernel, from the
-    newest committed PMC pass (scripts/pmc_mfma.py -> profiles/r<round>_<tag>_pmc_mfma.json); None when absent."""
-    import glob
+    js, name, stale = _newest_summary("r*_pmc_mfma.json")
+    if js is None:
+        return {"stale_summary_ignored": stale} if stale else None
     try:
-        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))[-1]
-        with open(newest) as f:
-            ks = json.load(f)["kernels"]
-        k = [r for r in ks if "gemm256_bf16_kernel<2, 0>" in r["kernel"]][0]
-        return {"mfma_busy_frac_of_cycles": k["mfma_util_of_cycles"], "shader_clock_ghz": k["shader_clock_ghz"],
-                "source": os.path.basename(newest)}
+        k = [r for r in js["kernels"] if "gemm256_bf16_kernel<2, 0" in r["kernel"]][0]
+        return {"mfma_busy_frac_of_cycles": k["mfma_util_of_cycles"], "shader_clock_ghz": k["shader_clock_ghz"], "source": name}
     except Exception:
         return None
 
 
-class _MetaBatch(dict):
-    """Placeholder for a batch owned by another rank: only its size is ever read."""
-
-
-def make_loader(own_batches, rank, world):
-    """Global batch list under round-robin ownership: entry i belongs to rank i % world."""
-    n_local = len(own_batches)
-    out = []
-    for j in range(n_local):
-        for r in range(world):
-            if r == rank:
-                out.append(own_batches[j])
-            else:
-                b = own_batches[j]
-                out.append(_MetaBatch(pixel_values=torch.empty(b["pixel_values"].shape, device="meta"),
-                                      labels=torch.empty(b["pixel_values"].shape[0], device="meta")))
-    return out
-
-
-def cpu_baseline(args, weights):
+def cpu_baseline(args, weights, n_eval, calib_n):
     """Oracle (kind="port": bit-exact restatement of the reference, pinned by tests/test_oracle_golden.py) timed on
     the host cores over a bounded sample; converted to the metric's unit with the step's own mix of passes."""
     from oracle import ref_cpu
@@ -91,23 +92,95 @@ def cpu_baseline(args, weights):
     model = build_from_flat(weights, "timm")
     g = torch.Generator().manual_seed(123)
     n1, n2, bs = args.cpu_sample, args.cpu_sample, 32
-    calib = [{"pixel_values": torch.randn(bs, 3, 224, 224, generator=g)} for _ in range(n1 // bs)]
-    evalb = [{"pixel_values": torch.randn(bs, 3, 224, 224, generator=g), "labels": torch.zeros(bs, dtype=torch.int64)}
+    img = int(weights["img"])
+    calib = [{"pixel_values": torch.randn(bs, 3, img, img, generator=g)} for _ in range(n1 // bs)]
+    evalb = [{"pixel_values": torch.randn(bs, 3, img, img, generator=g), "labels": torch.zeros(bs, dtype=torch.int64)}
              for _ in range(n2 // bs)]
     ref_cpu.ffn_activation_importance(model, calib[:1])            # warm-up (oneDNN primitive cache)
     t0 = time.time(); ref_cpu.ffn_activation_importance(model, calib); t1 = time.time()
     ref_cpu.top1_counts(model, evalb); t2 = time.time()
     r1, r2 = n1 / (t1 - t0), n2 / (t2 - t1)
     L = int(weights["depth"])
-    n_eval = args.eval_batches * args.batch
-    units = args.calib + (L + 1) * n_eval
-    step_s = args.calib / r1 + (L + 1) * n_eval / r2
+    units = calib_n + (L + 1) * n_eval
+    step_s = calib_n / r1 + (L + 1) * n_eval / r2
     return {"value": round(units / step_s, 3), "unit": "image-forwards/s", "cores": torch.get_num_threads(),
             "kind": "port", "prune_time_s_extrapolated": round(step_s, 1),
             "stage1_img_per_s": round(r1, 2), "eval_img_per_s": round(r2, 2),
-            "sample": f"ViT-B/16 bf16-autocast oracle: stage-1 scoring of {n1} images + top-1 eval of {n2} images "
-                      f"(batch {bs}); extrapolated to {args.calib} calib + {L + 1}x{n_eval} eval image-forwards; "
+            "sample": f"bf16-autocast oracle: stage-1 scoring of {n1} images + top-1 eval of {n2} images "
+                      f"(batch {bs}); extrapolated to {calib_n} calib + {L + 1}x{n_eval} eval image-forwards; "
                       f"model deep-copies of the reference not counted"}
+
+
+def act_l2_figure(eng, batch, tokens, d_int, dev):
+    """The HBM-bound kernel of the path on its own: the standalone activation-L2 accumulate (a2) over one layer's
+    activation of one calibration batch, outside the timed region (in the step it is fused into the fc1 epilogue and
+    reads nothing from HBM).  Algorithmic bytes = n*N*d_int*2 read once.  The calls ROTATE over enough
+    distinct activations to exceed the 256 MiB Infinity Cache, so the figure is HBM, not cache replay."""
+    one = batch * tokens * d_int * 2
+    nrot = max(8, -(-(320 << 20) // one))                        # >= 320 MiB in rotation
+    acts = [torch.randn(batch, tokens, d_int, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(nrot)]
+    import ctypes as C
+    ws = torch.empty(batch, d_int, dtype=torch.float32, device=dev)
+    outv = torch.empty(d_int, dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ptrs = [C.c_void_p(a.data_ptr()) for a in acts]
+
+    def call(i):          # the C entry point directly, buffers preallocated: the host must not be the limit of a 13 us kernel pair
+        eng.lib.ssp2_act_l2_accum(stream, ptrs[i % nrot], 0, batch, tokens, d_int, d_int, 0, 0, C.c_void_p(ws.data_ptr()),
+                                  C.c_void_p(outv.data_ptr()), d_int)
+    for i in range(nrot):
+        call(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3 * nrot
+    e0.record()
+    for i in range(reps):
+        call(i)
+    e1.record(); e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    gbps = one / (us * 1e-6) / 1e9
+    js, name, stale = _newest_summary("r*_pmc_act_l2.json")
+    return {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4),
+            "bytes_per_launch": one, "avg_launch_us": round(us, 2), "rotation": f"{nrot} distinct activations = {nrot * one >> 20} MiB (> 256 MiB Infinity Cache)",
+            "traffic": (js or {}).get("act_l2_norms_kernel", {}).get("hbm_bytes_per_launch") if js else None,
+            "traffic_source": name if js else ({"stale_summary_ignored": stale} if stale else None),
+            "kernel": "act_l2_norms_kernel<bf16> + score_colsum_kernel (standalone a2; 2 launches per call)"}
+
+
+def api_level(args, weights, calib, evalb, plan, dev, steps=3):
+    """The same prune through the reference-named API on a LIVE module that sits on the device (as the reference keeps
+    it): Auto2SSPInterface importances (attention first, then MLP, both enqueued before either is waited for) ->
+    prune_vit_mlp_width(precomputed_importance) -> prune_vit_attention_blocks(selected_indices).  The engine build
+    (weight ingest + workspace) happens inside the bracket: a fresh module per step has no cached engine."""
+    from ssp2vit import vit_pruning as vp
+    from ssp2vit.mask_conjunction import Auto2SSPInterface
+    from ssp2vit.modules import EngineViT
+    times, last = [], None
+    B = int(weights["depth"])
+    for _ in range(steps + 1):                                   # first pass = warm-up
+        model = EngineViT(weights).to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s2 = Auto2SSPInterface(model, evalb, device=dev, importance_mode="copy", batch_limit=len(evalb), min_remaining=512)
+        s1 = Auto2SSPInterface(model, calib, device=dev, batch_limit=None, min_remaining=512)
+        att_fin = s2._att_importance_deferred()                  # fit(): attention first (mask_conjunction.py:359-362) ...
+        mlp_fin = s1._mlp_importance_deferred()                  # ... then MLP; both enqueued, then awaited
+        att, mlp = att_fin(), mlp_fin()
+        res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[plan.per_block_neurons_to_prune] * B, min_remaining=512,
+                                     strategy="l1", collect_masks=True, precomputed_importance=[x.to(torch.float32) for x in mlp])
+        K = plan.blocks_to_prune
+        out = vp.prune_vit_attention_blocks(res["model"], sparsity=K / B, dataloader=None, device=dev, num_to_prune=K,
+                                            show_progress=False, selected_indices=[int(i) for i in torch.argsort(att)[:K]])
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        last = out["pruned_indices"]
+        vp.release_engines()
+        del model, res, out
+    t = sorted(times[1:])
+    return {"prune_time_s": round(t[len(t) // 2], 4), "steps": steps, "all_s": [round(x, 4) for x in times[1:]],
+            "selected_blocks": last,
+            "path": "EngineViT(weights).to(device) -> Auto2SSPInterface (deferred att + mlp importances) -> prune_vit_mlp_width("
+                    "precomputed_importance) -> prune_vit_attention_blocks(selected_indices); engine build inside the bracket"}
 
 
 def main():
@@ -116,26 +189,36 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="vit_base_patch16_224")
-    ap.add_argument("--calib", type=int, default=512, help="calibration images per GPU")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2),
+                    help="1: BASELINE configs[1], --calib/--eval-batches PER GPU (weak scaling); 2: configs[2], 2048 calib + 2560 eval "
+                         "images in total over the ranks, targets 0.25/0.375/0.5 from one stage-1 pass and one search (strong scaling)")
+    ap.add_argument("--calib", type=int, default=512, help="calibration images per GPU (config 1)")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--eval-batches", type=int, default=5)
+    ap.add_argument("--eval-batches", type=int, default=5, help="evaluation batches per GPU (config 1)")
     ap.add_argument("--calib-chunk", type=int, default=512, help="images per stage-1 forward (0 = one batch; see core.stage1_scores)")
-    ap.add_argument("--eval-chunk", type=int, default=0, help="images per search forward (0 = all eval images of the rank)")
+    ap.add_argument("--eval-chunk", type=int, default=0, help="images per search forward (0 = min(all eval images of the rank, 320))")
     ap.add_argument("--target", type=float, default=0.375)
+    ap.add_argument("--precision", default="bf16", choices=("bf16", "fp8"),
+                    help="fp8: QKV / fc1 / fc2 on e4m3 MFMA (opt-in, BASELINE configs[4]; its own tolerance, not the parity mode)")
     ap.add_argument("--cpu-sample", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the API-level secondary measurement")
+    ap.add_argument("--act-l2-only", action="store_true", help="only the standalone activation-L2 kernel loop (PMC passes)")
     ap.add_argument("--no-batch-candidates", action="store_true",
                     help="candidate-major search (one launch per candidate and block) instead of the layer-major one, "
                          "in which all candidates under way run a block in ONE launch (engine workspace for "
                          "(depth-1) x eval images)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="keep the batches in pinned HOST memory, as a dataloader hands them over: every step then pays "
-                         "the PCIe copy of 602 KB per image (the PCIe-inclusive rate of DESIGN.md; never the default)")
+                         "the PCIe copy (the PCIe-inclusive rate of DESIGN.md; never the default)")
+    ap.add_argument("--uint8", action="store_true",
+                    help="synthetic uint8 HWC images run through the GPU input pipeline (f4: resize -> ToTensor -> Normalize); with "
+                         "--host-inputs the 3-byte pixels cross PCIe and the pipeline runs inside the timed region")
     ap.add_argument("--two-streams", action="store_true",
                     help="run stage 1 and a share of the search candidates on a second HIP stream with its own engine "
-                         "workspace (2-5 %% faster end to end; per-launch durations then include the share of the "
-                         "machine lent to the other stream, so the roofline object is not a clean kernel figure)")
+                         "workspace (per-launch durations then include the share of the machine lent to the other stream, "
+                         "so the roofline object is not a clean kernel figure)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +237,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
         pg = dist.group.WORLD
 
-    from ssp2vit import core
+    from ssp2vit import core, dist as sdist
     from ssp2vit.engine import VitEngine
     from ssp2vit.planner import plan_from_stats, stats_from_shapes
     from ssp2vit.weights import VIT_CONFIGS, synthetic_weights
@@ -162,67 +245,121 @@ def main():
     img, patch, dim, heads, d_int, depth = VIT_CONFIGS[args.model]
     tokens = (img // patch) ** 2 + 1
     weights = synthetic_weights(args.model, classes=1000, seed=0, std=0.02, eps=1e-6, spread=4.0)
-    cap = max(args.batch, args.eval_batches * args.batch, args.calib_chunk)
+
+    # ---- how many batches this rank owns
+    if args.config == 2:
+        tot_cal_b, tot_ev_b = 2048 // args.batch, 2560 // args.batch
+        n_cal_b = len(range(rank, tot_cal_b, world)); n_ev_b = len(range(rank, tot_ev_b, world))
+        targets = [0.25, 0.375, 0.5]
+        calib_total, eval_total = tot_cal_b * args.batch, tot_ev_b * args.batch
+    else:
+        n_cal_b, n_ev_b = args.calib // args.batch, args.eval_batches
+        targets = [args.target]
+        calib_total, eval_total = world * n_cal_b * args.batch, world * n_ev_b * args.batch
+    n_calib, n_eval = n_cal_b * args.batch, n_ev_b * args.batch
+    eval_chunk = args.eval_chunk or min(n_eval, 320)
+    calib_chunk = min(args.calib_chunk or args.batch, max(n_calib, args.batch))
+
+    stats = stats_from_shapes(dim, depth, d_int, 1000, tokens, patch)
+    plans = [plan_from_stats(stats, t, min_remaining=512) for t in targets]
+    plan = plans[targets.index(args.target)] if args.target in targets else plans[0]
+
+    if args.act_l2_only:
+        eng = VitEngine(weights, device=dev, max_images=args.batch)
+        print(json.dumps(act_l2_figure(eng, args.batch, tokens, d_int, dev)), flush=True)
+        return
+    cap = max(args.batch, eval_chunk, calib_chunk)
     args.batch_candidates = not args.no_batch_candidates and not args.two_streams
     if args.batch_candidates:
-        cap = max(cap, depth * (args.eval_chunk or args.eval_batches * args.batch))
-    eng = VitEngine(weights, device=dev, max_images=cap)
+        cap = max(cap, depth * eval_chunk)
+    eng = VitEngine(weights, device=dev, max_images=cap, precision=args.precision)
     # --two-streams: stage 1 (calibration scores) and stage 2 (depth search on the dense model) are independent, and so
     # are the search candidates: with a second engine workspace (weights uploaded twice, 173 MB) on a second HIP stream
     # the memory-bound kernels of one stream (LayerNorm, attention, epilogue tails) overlap the matrix-bound kernels of
     # the other and the partial last round of a persistent GEMM is filled by the other stream's workgroups.
-    eng1 = VitEngine(weights, device=dev, max_images=max(args.batch, args.calib_chunk)) if args.two_streams else eng
+    eng1 = VitEngine(weights, device=dev, max_images=max(args.batch, calib_chunk), precision=args.precision) if args.two_streams else eng
     side = torch.cuda.Stream(dev) if args.two_streams else None
     d_ints = [d_int] * depth
-    plan = plan_from_stats(stats_from_shapes(dim, depth, d_int, 1000, tokens, patch), args.target, min_remaining=512)
+    twins = [eng.pruned_twin([d_int - p.per_block_neurons_to_prune] * depth, max_images=args.batch) for p in plans]
 
-    # synthetic ImageNet-shape inputs, resident in HBM before the timed region; every rank its own shard
+    # ---- synthetic ImageNet-shape inputs, resident in HBM before the timed region; every rank its own shard
     g = torch.Generator(device=dev).manual_seed(1 + rank)
-    n_cal_b = args.calib // args.batch
-    calib = [{"pixel_values": torch.randn(args.batch, 3, img, img, generator=g, device=dev)} for _ in range(n_cal_b)]
-    evalb = []
-    for _ in range(args.eval_batches):
-        px = torch.randn(args.batch, 3, img, img, generator=g, device=dev)
+    pp = None
+    if args.uint8:
+        from ssp2vit.preprocess import GpuPreprocessor
+        pp = GpuPreprocessor((img, img), img, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5), device=dev)
+
+    def fresh_pixels():
+        if pp is None:
+            return torch.randn(args.batch, 3, img, img, generator=g, device=dev), None
+        u8 = torch.randint(0, 256, (args.batch, img, img, 3), generator=g, device=dev, dtype=torch.uint8)
+        return pp(u8), u8
+
+    calib, evalb = [], []
+    for _ in range(n_cal_b):
+        px, u8 = fresh_pixels()
+        calib.append({"pixel_values": px, "u8": u8})
+    for _ in range(n_ev_b):
+        px, u8 = fresh_pixels()
         x = eng.embed(px); eng.layers(x, args.batch)
         _, pred, _ = eng.head(x, args.batch, want_pred=True)
-        evalb.append({"pixel_values": px, "labels": pred.long()})     # teacher labels: dense model's own argmax
-    if args.host_inputs:
-        calib = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in calib]
-        evalb = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in evalb]
-    calib_loader, eval_loader = make_loader(calib, rank, world), make_loader(evalb, rank, world)
-    n_eval = args.eval_batches * args.batch
+        evalb.append({"pixel_values": px, "labels": pred.long(), "u8": u8})     # teacher labels: dense model's own argmax
+
+    def as_loader(batches):
+        out = []
+        for b in batches:
+            d = {k: v for k, v in b.items() if k != "u8"}
+            if args.host_inputs:
+                if b["u8"] is not None:                                           # raw 3-byte pixels + the GPU pipeline
+                    d["pixel_values"] = b["u8"].cpu().pin_memory(); d["preprocess"] = pp
+                else:
+                    d["pixel_values"] = b["pixel_values"].cpu().pin_memory()
+                if "labels" in d:
+                    d["labels"] = d["labels"].cpu().pin_memory()
+            out.append(d)
+        return out
+    calib_loader, eval_loader = as_loader(calib), as_loader(evalb)            # this rank's batches only (sharded=True)
+
+    sdist.TIMING = args.config == 2 and pg is not None
 
     def step():
         # both stages are enqueued before the host waits for either: the a7 mask step runs on the CPU while the GPU
         # is still searching (the two stages are independent: stage 2 evaluates the dense model)
         if side is None:
             scores = core.stage1_scores(eng1, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
-                                        chunk_images=args.calib_chunk, defer=True)
+                                        chunk_images=calib_chunk, defer=True, sharded=True)
         else:
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 scores = core.stage1_scores(eng1, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
-                                            chunk_images=args.calib_chunk, defer=True)
+                                            chunk_images=calib_chunk, defer=True, sharded=True)
         # the side stream also takes a share of the search candidates behind its stage-1 launch (lead ~ the stage-1
         # work expressed in block passes of the search chunk)
         search = core.depth_search_counts(eng, eval_loader, depth, batch_limit=None, process_group=pg,
-                                          chunk_images=args.eval_chunk or n_eval, defer=True,
+                                          chunk_images=eval_chunk, defer=True,
                                           aux_engine=None if side is None else eng1, aux_stream=side,
-                                          aux_lead=args.calib * depth / max(1, args.eval_chunk or n_eval),
-                                          batch_candidates=args.batch_candidates and side is None)
+                                          aux_lead=n_calib * depth / max(1, eval_chunk),
+                                          batch_candidates=args.batch_candidates and side is None, sharded=True)
         imps = scores()
-        masks = []
-        t = plan.per_block_neurons_to_prune
-        for imp in imps:                                              # a7 mask step (host, 12 x 3072)
-            keep, _ = torch.sort(torch.argsort(imp, descending=True)[: imp.numel() - t])
-            m = torch.ones(imp.numel(), dtype=torch.int16); m[keep] = 0
-            masks.append(m)
+        all_masks = []
+        for p in plans:                                                   # a7 mask step per target (host, 12 x 3072)
+            t = p.per_block_neurons_to_prune
+            masks = []
+            for imp in imps:
+                keep, _ = torch.sort(torch.argsort(imp, descending=True)[: imp.numel() - t])
+                m = torch.ones(imp.numel(), dtype=torch.int16); m[keep] = 0
+                masks.append(m)
+            all_masks.append(masks)
         base, cand, total = search()
         impact = torch.tensor(core.impacts_from_counts(base, cand, total), dtype=torch.float32)
-        blocks = sorted(int(i) for i in torch.argsort(impact)[: plan.blocks_to_prune])   # a9 (auto_2ssp.py:857)
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
-        return imps, impact, masks, blocks
+        chosen = []
+        for p, masks, twin in zip(plans, all_masks, twins):
+            blocks = sorted(int(i) for i in torch.argsort(impact)[: p.blocks_to_prune])   # a9 (auto_2ssp.py:857)
+            eng.apply_into(twin, masks, blocks)                            # a8 + a9 apply: gathers into the pruned twin
+            chosen.append(blocks)
+        return imps, impact, all_masks, chosen
 
     def sync_all():
         if pg is not None:
@@ -232,22 +369,23 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    if sdist.TIMING:
+        sdist.collective_ms()
     prof = None
     if not args.no_roofline:
         prof = eng.profile("gemm_fc1"); prof.__enter__()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     t0 = time.perf_counter()
-    s1_ms = 0.0
     for _ in range(args.steps):
         out = step()
     sync_all()
     elapsed = time.perf_counter() - t0
     if prof is not None:
         prof.__exit__(None, None, None)
+    coll = sdist.collective_ms() if sdist.TIMING else None
 
     # stage-1-only rate (secondary figure, separate timed loop so the headline region stays untouched)
     sync_all(); t1 = time.perf_counter()
-    core.stage1_scores(eng1, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg, chunk_images=args.calib_chunk)
+    core.stage1_scores(eng1, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg, chunk_images=calib_chunk, sharded=True)
     sync_all(); s1_s = time.perf_counter() - t1
 
     el = torch.tensor([elapsed, s1_s], dtype=torch.float64, device=dev)
@@ -256,60 +394,63 @@ def main():
     elapsed, s1_s = float(el[0]), float(el[1])
 
     if rank == 0:
-        units_step = args.calib + (depth + 1) * n_eval
-        value = world * units_step * args.steps / elapsed
+        units_step = calib_total + (depth + 1) * eval_total                             # whole job, all ranks
+        value = units_step * args.steps / elapsed
         tail = 2.0 * dim / (4 * dim + 2 * d_int + 2 * tokens)                            # cost of the CLS-only last block / a full block
-        executed = args.calib * depth + n_eval * ((depth - 1) + (depth - 1) * depth // 2 + (depth + 1) * tail)   # block passes per step
-        reference_equiv = args.calib * depth + n_eval * depth * (depth + 1)
+        executed = calib_total * depth + eval_total * ((depth - 1) + (depth - 1) * depth // 2 + (depth + 1) * tail)   # block passes per step
+        reference_equiv = calib_total * depth + eval_total * depth * (depth + 1)
+        tdesc = ", ".join(f"{t} (K={p.blocks_to_prune}, t={p.per_block_neurons_to_prune})" for t, p in zip(targets, plans))
+        per = "in total over the ranks" if args.config == 2 else "/GPU"
         line = {
             "metric": "2ssp_prune_image_forwards_per_sec", "value": round(value, 1), "unit": "image-forwards/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic, pinned host batches copied over PCIe inside the timed region" if args.host_inputs else "synthetic",
-            "config": {"workload": f"{args.model}, {args.calib} calib images/GPU, full 2SSP @ {args.target} "
-                                   f"(K={plan.blocks_to_prune} blocks, t={plan.per_block_neurons_to_prune} neurons), "
-                                   f"one-shot depth search over {n_eval} eval images/GPU, batch {args.batch}",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True,
+            "scaling": "strong" if args.config == 2 else "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "fp8 (e4m3 QKV/fc1/fc2 GEMMs, bf16 elsewhere)",
+            "data": ("synthetic" + (", uint8 HWC through the GPU input pipeline" if args.uint8 else "")
+                     + (", pinned host batches copied over PCIe inside the timed region" if args.host_inputs else "")),
+            "config": {"workload": f"{args.model}, {calib_total if args.config == 2 else n_calib} calib images {per}, full 2SSP @ {tdesc}, "
+                                   f"one-shot depth search over {eval_total if args.config == 2 else n_eval} eval images {per}, batch {args.batch}, "
+                                   f"select + apply into a pruned engine inside the step",
+                       "baseline_config": f"BASELINE.json configs[{args.config}]",
                        "weights": "random-init trunc-normal(0.02), fc1 rows log-uniform x[1/4,4], seed 0",
-                       "parallelism": f"dp{world} (batches round-robin, weights replicated)"},
+                       "parallelism": f"dp{world} (batches dealt round-robin, every rank's loader yields only its own, weights replicated)"},
             "prune_time_s": round(elapsed / args.steps, 4),
-            "calib_images_per_sec": round(world * args.calib / s1_s, 1),
+            "calib_images_per_sec": round(calib_total / s1_s, 1),
             "executed_block_pass_fraction": round(executed / reference_equiv, 4),
-            "selected_blocks": out[3], "pruned_neurons_per_block": plan.per_block_neurons_to_prune,
+            "selected_blocks": out[3][targets.index(args.target)] if args.target in targets else out[3][0],
+            "selected_blocks_per_target": {str(t): b for t, b in zip(targets, out[3])},
+            "pruned_neurons_per_block": plan.per_block_neurons_to_prune,
             "streams": 2 if args.two_streams else 1, "search": "layer-major" if args.batch_candidates else "candidate-major",
         }
+        if coll is not None:
+            line["collectives"] = {"backend": "nccl (RCCL)", "world_size": world,
+                                   "device_ms_per_step": {k: round(v / args.steps, 3) for k, v in coll.items()}}
         if prof is not None and prof.launches:
             # dominant kernel family: fc1 (+bias +erf-GELU; + fused activation-L2 partials in stage 1).
             # achieved = algorithmic flops (2*M*N*K summed over the recorded launches) / summed HIP-event durations.
             ach = prof.flops / (prof.total_ms * 1e-3) / 1e12
+            peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else FP8_MFMA_PEAK_TFLOPS
             lm = f", x 1..{depth - 1} in the layer-major search" if args.batch_candidates else ""
-            line["roofline"] = {"bound": "mfma", "kernel": "fc1 GEMM family: gemm256_bf16_kernel<EPI_FC1,SCORE> persistent 256x256 (stage 1: + fused activation-L2 partials; search passes: SCORE=0) and gemm_bf16_kernel<EPI_FC1> 128x128 (CLS tail); bias + erf-GELU fused",
-                                "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(), "pmc": pmc_mfma(),
+            traffic, tsrc = pmc_traffic()
+            line["roofline"] = {"bound": "mfma", "kernel": "fc1 GEMM family: gemm256 persistent 256x256 <EPI_FC1,SCORE> (stage 1: + fused activation-L2 partials; search passes: SCORE=0) and gemm_bf16_kernel<EPI_FC1> 128x128 (CLS tail); bias + erf-GELU fused",
+                                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc, "pmc": pmc_mfma(),
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
                                 "flops_per_launch_avg": prof.flops / prof.launches,
-                                "shapes": f"[{eng.rows(min(args.calib, args.calib_chunk or args.batch), args.batch)} | {(args.eval_chunk or n_eval) * tokens} | {n_eval}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk{lm} | CLS tail)"}
+                                "shapes": f"[{eng.rows(min(n_calib, calib_chunk), args.batch)} | {eval_chunk * tokens} | {eval_chunk}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk{lm} | CLS tail)"}
         if not args.no_roofline:
-            # the HBM-bound kernel of the path on its own: the standalone activation-L2 accumulate (a2) over one
-            # layer's activation of one calibration batch, outside the timed region (in the step it is fused into the
-            # fc1 epilogue and reads nothing from HBM).  Algorithmic bytes = n*N*d_int*2 read once.
-            act = torch.randn(args.batch, tokens, d_int, device=dev, dtype=torch.float32).to(torch.bfloat16)
-            for _ in range(3):
-                eng.act_l2_accum(act)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 20
-            e0.record()
-            for _ in range(reps):
-                eng.act_l2_accum(act)
-            e1.record(); e1.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / reps
-            gbps = act.numel() * 2 / (us * 1e-6) / 1e9
-            line["act_l2_kernel"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
-                                     "frac": round(gbps / 8000.0, 4), "bytes_per_launch": act.numel() * 2,
-                                     "avg_launch_us": round(us, 2),
-                                     "kernel": "act_l2_norms_kernel<bf16> + score_colsum_kernel (standalone a2; 2 launches per call)"}
+            line["act_l2_kernel"] = act_l2_figure(eng, args.batch, tokens, d_int, dev)
+        if world == 1 and not args.no_api and args.config == 1 and args.precision == "bf16":
+            eng.close(); eng1.close()
+            for t in twins:
+                t.close()
+            torch.cuda.empty_cache()
+            api_calib = [{"pixel_values": b["pixel_values"]} for b in calib_loader]
+            line["api"] = api_level(args, weights, api_calib, eval_loader, plan, dev)
+            line["api"]["vs_core_step"] = round(line["api"]["prune_time_s"] / line["prune_time_s"], 3)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, weights)
+            line["cpu_baseline"] = cpu_baseline(args, weights, n_eval, n_calib)
         print(json.dumps(line), flush=True)
     if pg is not None:
         torch.distributed.destroy_process_group()

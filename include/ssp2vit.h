@@ -127,7 +127,19 @@ int ssp2_tail(ssp2_handle h, const float* x_dev, int n, int attn_skip_last, floa
 int ssp2_prune_ffn(ssp2_handle h, int layer, const int32_t* keep_host, int n_keep);
 /* a6/a9 applied for good: block `layer` loses its attention sub-module (always bypassed from now on). */
 int ssp2_drop_attention(ssp2_handle h, int layer);
+int ssp2_restore_attention(ssp2_handle h, int layer);      /* undo ssp2_drop_attention (the weights were never freed) */
 int ssp2_d_int(ssp2_handle h, int layer);
+
+/* a8 / a9 "apply" without touching the dense engine — what keeps a pruned model next to the original
+ * (the reference deep-copies for that, mask_conjunction.py:339): `dst` is a second engine of the same architecture
+ * whose blocks were created with the PRUNED widths.
+ *   ssp2_clone_weights   copies every tensor whose shape agrees (embeddings, attention, norms, head, and the FFN of
+ *                        blocks with equal d_int) device to device on dst's stream;
+ *   ssp2_prune_ffn_into  gathers the kept neurons of src's block `layer` (fc1 rows + bias, fc2 columns) into dst's
+ *                        block, n_keep == dst's d_int of that block; asynchronous on dst's stream, no allocation after
+ *                        the first call, bit-identical to ssp2_prune_ffn on a copy. */
+int ssp2_clone_weights(ssp2_handle dst, ssp2_handle src);
+int ssp2_prune_ffn_into(ssp2_handle dst, ssp2_handle src, int layer, const int32_t* keep_host, int n_keep);
 
 /* a2 standalone (the hook body on an activation tensor that already sits in HBM):
  *   act_dev bf16 (dtype 0) or f32 (dtype 1), [n, tokens, ld] with the first d columns used;

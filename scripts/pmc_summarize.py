@@ -4,7 +4,7 @@ Units / corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: both count
 reports exactly half of the bytes of a wide coalesced streaming read (16 B/lane, global_load and LDS-DMA alike), so
 it is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.  Infinity-Cache hits are counted as traffic.
 """
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 
 def load(d, counter):
@@ -29,6 +29,8 @@ rows.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
 fc1 = [r for r in rows if "gemm_bf16_kernel<2," in r["kernel"] or "gemm256_bf16_kernel<2" in r["kernel"]]   # EPI_FC1, both tile shapes
 n = sum(r["launches"] for r in fc1)
 avg = sum(r["launches"] * r["hbm_bytes_per_launch"] for r in fc1) / max(1, n)
-print(json.dumps({"unit": "bytes per launch; FETCH_SIZE doubled (gfx950), KiB->B; Infinity-Cache hits count as traffic",
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2ssp-x-vit_amd"))
+from ssp2vit import _lib   # noqa: E402  (bench.py only trusts a summary recorded at the running library's source hash)
+print(json.dumps({"lib_source_hash": _lib._source_hash(), "unit": "bytes per launch; FETCH_SIZE doubled (gfx950), KiB->B; Infinity-Cache hits count as traffic",
                   "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 (two passes)",
                   "fc1_family": {"launches": n, "avg_hbm_bytes_per_launch": round(avg)}, "kernels": rows[:14]}, indent=1))

@@ -906,3 +906,92 @@ def test_torch_ops_give_the_same_bits_as_the_ctypes_path(gpu):
     assert torch.equal(ops.act_l2_accum(act, "bf16_ref"), eng.act_l2_accum(act, "bf16_ref"))
     with pytest.raises(RuntimeError):
         ops.forward(eng, px.cpu())
+
+
+def test_apply_into_a_pruned_twin_equals_an_engine_built_from_sliced_weights(gpu):
+    """bench.py's "apply" step: engine.apply_into gathers the kept FFN neurons and drops the chosen attention blocks into
+    a SECOND engine (ssp2_clone_weights + ssp2_prune_ffn_into), leaving the dense engine as it was.  The twin must equal,
+    bit for bit, a fresh engine built from the host-sliced module (reference surgery, src/vit_pruning.py:297-311,
+    :499-504); re-applying other masks / blocks into the same twin must equal the fresh engine for those; the dense
+    engine's logits must not move."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp, weights as W
+    from ssp2vit.engine import VitEngine
+    from ssp2vit._lib import Ssp2Error
+    w = W.synthetic_weights("vit_tiny_patch16_224", classes=10, seed=3, std=0.05, eps=1e-6, bias_std=0.02)
+    g = torch.Generator().manual_seed(12)
+    px = torch.randn(5, 3, 224, 224, generator=g).to(gpu)
+    eng = VitEngine(w, max_images=5)
+    dense = eng.forward_logits(px).clone()
+    imps = [eng.forward_scores(px, "pre_gelu")[0][l, :768].cpu() for l in range(12)]
+    twin = eng.pruned_twin([768 - 304] * 12, max_images=5)
+    for drop, seed in (([3, 11], 0), ([0, 5, 6], 1)):
+        scores = [imp if seed == 0 else imp.flip(0) for imp in imps]              # second round: other neurons survive
+        model = build_from_flat(w, "timm")
+        res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[304] * 12, min_remaining=256, collect_masks=True,
+                                     precomputed_importance=scores)
+        for b in drop:
+            vp._apply_bypass(model, b)
+        eng.apply_into(twin, res["ffn_prune_masks"], drop)
+        fresh = VitEngine(W.from_module(model), max_images=5)
+        assert torch.equal(twin.forward_logits(px), fresh.forward_logits(px)), drop
+        a, b = twin.forward_scores(px, "post_gelu")[0], fresh.forward_scores(px, "post_gelu")[0]
+        assert torch.equal(a[:, :464], b[:, :464])
+        fresh.close()
+    assert torch.equal(eng.forward_logits(px), dense)                              # the dense engine is untouched
+    with pytest.raises(Ssp2Error):
+        eng.apply_into(twin, [[0] * 768] * 12, [])                                 # keep list wider than the twin's blocks
+
+
+def test_uint8_batches_through_the_gpu_pipeline_give_the_fp32_path_bits(gpu):
+    """f4 wired into the path: a loader that hands over raw uint8 HWC images (+ their GpuPreprocessor) must give the same
+    scores and counts, bit for bit, as a loader that hands over the fp32 tensors the same pipeline produced — host
+    (pinned, copied on the copy stream) or device resident, with a ragged last batch."""
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.preprocess import GpuPreprocessor
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=4, std=0.05, eps=1e-6, bias_std=0.02)
+    eng = VitEngine(w, max_images=12 * 24)
+    pp = GpuPreprocessor((32, 32), 224, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+    g = torch.Generator().manual_seed(6)
+    raw = [torch.randint(0, 256, (n, 32, 32, 3), generator=g, dtype=torch.uint8) for n in (8, 8, 5)]
+    labels = [torch.randint(0, 10, (r.shape[0],), generator=g) for r in raw]
+    f32 = [{"pixel_values": pp(r).clone(), "labels": lb} for r, lb in zip(raw, labels)]
+    u8_host = [{"pixel_values": r.pin_memory(), "labels": lb, "preprocess": pp} for r, lb in zip(raw, labels)]
+    u8_dev = [{"pixel_values": r.to(gpu), "labels": lb.to(gpu), "preprocess": pp} for r, lb in zip(raw, labels)]
+    d_ints = [768] * 12
+    ref_s = core.stage1_scores(eng, f32, d_ints, "pre_gelu", chunk_images=24)
+    ref_c = core.depth_search_counts(eng, f32, 12, batch_limit=None, chunk_images=24)
+    for loader in (u8_host, u8_dev):
+        got = core.stage1_scores(eng, loader, d_ints, "pre_gelu", chunk_images=24)
+        assert all(torch.equal(a, b) for a, b in zip(got, ref_s))
+        assert core.depth_search_counts(eng, loader, 12, batch_limit=None, chunk_images=24) == ref_c
+    with pytest.raises(ValueError):
+        core.stage1_scores(eng, [{"pixel_values": raw[0]}], d_ints, "pre_gelu")     # uint8 without its preprocessor
+
+
+def test_api_on_a_device_resident_module_matches_the_host_resident_one(gpu):
+    """The reference keeps its model on the device.  A module whose parameters live on the GPU is ingested in place
+    (ssp2_load_tensor_dev: rounding + padding in a kernel); Auto2SSPInterface.fit() on it — layer-major search, both
+    stages enqueued before either is awaited — must give exactly what the host-resident module gives."""
+    from ssp2vit import vit_pruning as vp
+    from ssp2vit.mask_conjunction import Auto2SSPInterface
+    from ssp2vit.modules import EngineViT
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=7, std=0.05, eps=1e-6, bias_std=0.02)
+    g = torch.Generator().manual_seed(8)
+    batches = []
+    for n in (16, 16, 9):
+        batches.append({"pixel_values": torch.randn(n, 3, 224, 224, generator=g), "labels": torch.randint(0, 10, (n,), generator=g)})
+    outs = []
+    for place in ("cpu", "cuda"):
+        m = EngineViT(w).to(place)
+        att, mlp = Auto2SSPInterface(m, batches, device="cuda", importance_mode="copy", batch_limit=5).fit()
+        eng = vp.engine_for(m, "cuda", 1)
+        assert eng.max_images >= 12 * 41                                          # the layer-major workspace was asked for
+        outs.append((att, mlp, m(batches[0]["pixel_values"].to(gpu)).cpu()))
+        vp.release_engines()
+    assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert outs[0][0].shape == (12,) and len(outs[0][1]) == 12

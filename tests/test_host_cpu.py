@@ -213,19 +213,30 @@ def test_empty_and_limited_loaders_like_reference():
     assert (base, cand, total) == (0, [0, 0, 0, 0], 0)
 
 
-def test_bench_reads_the_committed_pmc_summaries():
-    """bench.py fills roofline.traffic and roofline.pmc from the newest committed rocprofv3 PMC summaries (counters
-    cannot be read from inside the process): the files under profiles/ must keep the fields it reads."""
+def test_bench_only_trusts_pmc_summaries_of_the_running_source(tmp_path, monkeypatch):
+    """bench.py fills roofline.traffic / roofline.pmc from committed rocprofv3 PMC summaries (counters cannot be read
+    from inside the process) — but only from a summary whose recorded `lib_source_hash` equals the hash of the sources
+    the running library was built from; any other file is reported as stale and ignored."""
     import importlib.util
+    import json as js
+    from ssp2vit import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)                      # main() is guarded: nothing runs
-    traffic = bench.pmc_traffic()
-    assert isinstance(traffic, int) and traffic > 100e6                      # bytes per fc1 launch
-    pmc = bench.pmc_mfma()
-    assert pmc is not None and 0.2 < pmc["mfma_busy_frac_of_cycles"] < 1.0 and 1.0 < pmc["shader_clock_ghz"] < 2.6
-    assert os.path.exists(os.path.join(root, "profiles", pmc["source"]))
+    prof = tmp_path / "profiles"; prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic() == (None, None) and bench.pmc_mfma() is None
+    (prof / "r09_a_pmc_traffic.json").write_text(js.dumps({"lib_source_hash": "deadbeef", "fc1_family": {"avg_hbm_bytes_per_launch": 5}}))
+    assert bench.pmc_traffic() == (None, {"stale_summary_ignored": "r09_a_pmc_traffic.json"})
+    (prof / "r09_b_pmc_traffic.json").write_text(js.dumps({"lib_source_hash": _lib._source_hash(), "fc1_family": {"avg_hbm_bytes_per_launch": 123456789}}))
+    assert bench.pmc_traffic() == (123456789, {"source": "r09_b_pmc_traffic.json"})
+    (prof / "r09_b_pmc_mfma.json").write_text(js.dumps({"lib_source_hash": _lib._source_hash(), "kernels": [
+        {"kernel": "void gemm256_bf16_kernel<2, 0, 0>", "mfma_util_of_cycles": 0.5, "shader_clock_ghz": 1.9}]}))
+    assert bench.pmc_mfma() == {"mfma_busy_frac_of_cycles": 0.5, "shader_clock_ghz": 1.9, "source": "r09_b_pmc_mfma.json"}
+    # the summary writers record the hash
+    for script in ("pmc_summarize.py", "pmc_mfma.py", "pmc_act_l2.sh"):
+        assert "lib_source_hash" in open(os.path.join(root, "scripts", script)).read()
 
 
 def test_host_batches_pass_through_on_a_cpu_engine():

@@ -124,6 +124,10 @@ def test_vit_b16_headline_geometry_pins_the_oracle():
     the GPU box needs no CPU forward at this size).  ~10 s on 8 cores."""
     import os
     from ssp2vit.weights import synthetic_weights
+    # bf16 GEMMs of this size are split over the threads by oneDNN, and the split decides the fp32 summation order: the
+    # golden was captured with 8 threads (make_golden.py), an earlier test of the session may have lowered the count
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(8)
     z = dict(np.load(os.path.join(GOLDEN, "vit_b16_2x32.npz")))
     w = synthetic_weights("vit_base_patch16_224", classes=1000, seed=0, std=0.02, eps=1e-6, spread=4.0)
     chk = sum(float(v.double().sum()) for v in w.values() if isinstance(v, torch.Tensor))
@@ -142,3 +146,4 @@ def test_vit_b16_headline_geometry_pins_the_oracle():
     # stage-2 selection rule on the reference's own impact vector (auto_2ssp.py:857, K = 5)
     assert ref_cpu.select_blocks_torch_argsort(torch.from_numpy(z["att_imp"]), 5) == z["s2_selected_k5"].tolist()
     assert z["att_imp"].shape == (12,) and float(z["top1"]) == 1.0 and sum(len(z[f"labels.{i}"]) for i in range(2)) == 64
+    torch.set_num_threads(old_threads)
