@@ -67,6 +67,9 @@ static inline float bf2f(uint16_t b) {
 
 // ------------------------------------------------------------------------------------------------ engine
 struct Mat {            // bf16 weight matrix [rows_pad, ld] zero padded
+  uint8_t* w8 = nullptr;  // fp8 mode: e4m3 image [rows_pad, ld8] + one dequantisation scale per row (ssp2_set_precision)
+  float* wscale = nullptr;
+  int ld8 = 0, ld8_cap = 0;
   bf16* w = nullptr;
   float* b = nullptr;   // [rows_pad] fp32 holding bf16-rounded values
   int rows = 0, rows_pad = 0, cols = 0, ld = 0;
@@ -105,6 +108,9 @@ struct ssp2_engine {
   bf16 *q_cls = nullptr, *o_cls = nullptr, *h_cls = nullptr, *act_cls = nullptr;
   float *slab = nullptr, *norms = nullptr, *logits = nullptr;
 
+  bool fp8 = false;             // ssp2_set_precision(SSP2_PREC_FP8): QKV / fc1 / fc2 of launches with >= 4096 rows on e4m3 MFMA
+  uint8_t *hbuf8 = nullptr, *act8 = nullptr;   // LayerNorm output / FFN activation as e4m3 bytes
+  int ld8_dim = 0, ld8_int_max = 0;
   float* stage_f32 = nullptr;   // staging buffer of ssp2_load_tensor (host sources)
   size_t stage_cap = 0;
 
@@ -151,18 +157,19 @@ struct ProfScope {
 // Large-M projections go to the 256 x 256 tile kernel (bit-identical results, fewer LDS-DMA issues per MFMA);
 // everything else (small M, fused fc1 epilogue, patch embed, head) stays on the 128 x 128 kernel.
 static const int kBigTileMinRows = 4096;
-template <int EPI, int SCORE = 0>
+template <int EPI, int SCORE = 0, bool F8 = false>
 static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
   g.group_m = 0;                 // plain N-fastest tile order (group_m means column groups here, see gemm256.hip.h)
+  if (F8 && (g.K % 128 || !g.wscale)) return fail(SSP2_EINVAL, "fp8 GEMM needs K %% 128 == 0 and per-row weight scales (K=%d)", g.K);
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS));
     attr_done = true;
   }
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
-  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE>), dim3(std::min(g.tiles_m * g.tiles_n, e->n_cu)), dim3(512), G256::LDS, e->stream, g);
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE, F8>), dim3(std::min(g.tiles_m * g.tiles_n, e->n_cu)), dim3(512), G256::LDS, e->stream, g);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -194,12 +201,12 @@ static int launch_gemm_small(ssp2_engine* e, GemmArgs g, int klass) {
 }
 
 static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const float* g, const float* b, bf16* y,
-                     int out_ld, int rows, int D, RowMap gather = RowMap{0, 0, 0}) {
+                     int out_ld, int rows, int D, RowMap gather = RowMap{0, 0, 0}, uint8_t* y8 = nullptr) {
   ProfScope ps(e, SSP2_K_LN);
   dim3 grid((rows + 3) / 4), blk(256);
   // one instantiation per row width in 256-element steps: the row lives in MAXV float4 registers per lane, and a
   // wider instantiation than needed drags predicated dead chunks along (ViT-L/16 on <8>: 3.1 TB/s; on <4>: see DESIGN)
-#define LN_CASE(V) hipLaunchKernelGGL(layernorm_bf16_kernel<V>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather)
+#define LN_CASE(V) hipLaunchKernelGGL(layernorm_bf16_kernel<V>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8)
   if (D <= 256 * 1) LN_CASE(1);
   else if (D <= 256 * 2) LN_CASE(2);
   else if (D <= 256 * 3) LN_CASE(3);
@@ -271,6 +278,8 @@ static int launch_attn(ssp2_engine* e, int n, RowMap rm, bool cls_only = false) 
 
 static int act_l2_impl(void* stream, const void* act, int dtype, int n, RowMap rm, int d, int ld, int chain, int group,
                        float* norms_ws, float* out, size_t out_stride);
+// the unfused scoring path (models with < 128 tokens) reads the bf16 activation back: it stays on the bf16 kernels
+static inline bool fused_ok_for_fp8(int score_site, int tokens) { return score_site == 0 || tokens >= GEMM_BM; }
 
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" {
@@ -339,7 +348,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
   TRY(dalloc(e, &e->actbuf, M * e->ld_int_max, true));
   if (e->tokens < GEMM_BM) TRY(dalloc(e, &e->prebuf, M * e->ld_int_max, true));
   TRY(dalloc(e, &e->slab, tiles_m * 2 * e->ld_int_max, true));
-  TRY(dalloc(e, &e->norms, (size_t)d.max_images * e->ld_int_max, true));
+  TRY(dalloc(e, &e->norms, (size_t)2 * d.max_images * e->ld_int_max, true));   // [2 token halves][n][ld] for the standalone L2 kernel
   TRY(dalloc(e, &e->cls_h, (size_t)d.max_images * d.dim, true));
   TRY(dalloc(e, &e->x_cls, (size_t)d.max_images * d.dim, true));
   TRY(dalloc(e, &e->q_cls, (size_t)d.max_images * d.dim, true));
@@ -476,6 +485,40 @@ static int check_n(ssp2_engine* e, int n, int group = 0) {
   return 0;
 }
 
+// ---- fp8 (e4m3) weight images --------------------------------------------------------------------------------------
+static int quantise_mat(ssp2_engine* e, Mat& m) {
+  const int ld8 = ceil_to(m.cols, 128);
+  if (!m.w8 || m.ld8_cap < ld8) {
+    if (dalloc(e, &m.w8, (size_t)m.rows_pad * ld8, false)) return SSP2_ENOMEM;
+    m.ld8_cap = ld8;
+  }
+  if (!m.wscale && dalloc(e, &m.wscale, (size_t)m.rows_pad, false)) return SSP2_ENOMEM;
+  m.ld8 = ld8;
+  hipLaunchKernelGGL(quant_rows_e4m3_kernel, dim3((m.rows_pad + 3) / 4), dim3(256), 0, e->stream, m.w, m.ld, m.w8, ld8, m.wscale, m.rows, m.cols, m.rows_pad);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ssp2_set_precision(ssp2_handle e, int mode) {
+  if (!e) return fail(SSP2_EINVAL, "null handle");
+  if (mode == SSP2_PREC_BF16) { e->fp8 = false; return 0; }
+  if (mode != SSP2_PREC_FP8) return fail(SSP2_EINVAL, "unknown precision %d", mode);
+  int rc;
+  for (int l = 0; l < e->d.depth; ++l) {
+    Layer& L = e->layers[l];
+    if (!(L.qkv.w_set && L.fc1.w_set && L.fc2.w_set)) return fail(SSP2_ESTATE, "set_precision(fp8): layer %d weights not loaded yet", l);
+    if ((rc = quantise_mat(e, L.qkv)) || (rc = quantise_mat(e, L.fc1)) || (rc = quantise_mat(e, L.fc2))) return rc;
+  }
+  if (!e->hbuf8) {
+    e->ld8_dim = ceil_to(e->d.dim, 128);
+    e->ld8_int_max = ceil_to(e->ld_int_max, 128);
+    if ((rc = dalloc(e, &e->hbuf8, (size_t)e->rows_cap * e->ld8_dim, true))) return rc;
+    if ((rc = dalloc(e, &e->act8, (size_t)e->rows_cap * e->ld8_int_max, true))) return rc;
+  }
+  e->fp8 = true;
+  return 0;
+}
+
 int ssp2_embed(ssp2_handle e, const float* pixels_dev, int n, float* x_dev, int group) {
   int rc;
   if ((rc = check_n(e, n, group))) return rc;
@@ -521,33 +564,57 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
     const bool skip = L.attn_dropped || (attn_skip && attn_skip[l]);
     if (!(L.ln_set[2] && L.ln_set[3] && L.fc1.w_set && L.fc1.b_set && L.fc2.w_set && L.fc2.b_set))
       return fail(SSP2_ESTATE, "layer %d MLP weights not loaded", l);
+    // fp8 mode: the three large projections of a launch with >= 4096 rows run on e4m3 operands (LayerNorm and the fc1
+    // epilogue write the activation as e4m3 bytes); attention, the out-projection and small launches stay bf16
+    const bool f8 = e->fp8 && M >= kBigTileMinRows;
     if (!skip) {
       if (!(L.ln_set[0] && L.ln_set[1] && L.qkv.w_set && L.qkv.b_set && L.proj.w_set && L.proj.b_set))
         return fail(SSP2_ESTATE, "layer %d attention weights not loaded", l);
-      if ((rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, e->hbuf, D, M, D))) return rc;
       GemmArgs q{};
-      q.A = e->hbuf; q.lda = D; q.W = L.qkv.w; q.ldw = L.qkv.ld; q.bias = L.qkv.b;
-      q.M = M; q.N = 3 * D; q.K = D; q.tiles_n = L.qkv.rows_pad / GEMM_BN; q.out = e->qkvbuf; q.ldo = 3 * D;
-      if ((rc = launch_gemm<EPI_BF16>(e, q, SSP2_K_GEMM_QKV))) return rc;
+      q.bias = L.qkv.b; q.M = M; q.N = 3 * D; q.tiles_n = L.qkv.rows_pad / GEMM_BN; q.out = e->qkvbuf; q.ldo = 3 * D;
+      if (f8) {
+        if ((rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
+        q.A = (const bf16*)e->hbuf8; q.lda = e->ld8_dim; q.W = (const bf16*)L.qkv.w8; q.ldw = L.qkv.ld8; q.K = e->ld8_dim; q.wscale = L.qkv.wscale;
+        if ((rc = launch_gemm256<EPI_BF16, 0, true>(e, q, SSP2_K_GEMM_QKV))) return rc;
+      } else {
+        if ((rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, e->hbuf, D, M, D))) return rc;
+        q.A = e->hbuf; q.lda = D; q.W = L.qkv.w; q.ldw = L.qkv.ld; q.K = D;
+        if ((rc = launch_gemm<EPI_BF16>(e, q, SSP2_K_GEMM_QKV))) return rc;
+      }
       if ((rc = launch_attn(e, n, rm))) return rc;
       GemmArgs p{};
       p.A = e->obuf; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.bias = L.proj.b;
       p.M = M; p.N = D; p.K = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = x; p.ldx = D;
       if ((rc = launch_gemm<EPI_RESID>(e, p, SSP2_K_GEMM_PROJ))) return rc;
     }
-    if ((rc = launch_ln(e, x, D, L.ln2_g, L.ln2_b, e->hbuf, D, M, D))) return rc;
+    const int ld8_int = ceil_to(L.ld_int, 128);
     GemmArgs f{};
-    f.A = e->hbuf; f.lda = D; f.W = L.fc1.w; f.ldw = L.fc1.ld; f.bias = L.fc1.b;
-    f.M = M; f.N = L.ld_int; f.K = D; f.tiles_n = L.fc1.rows_pad / GEMM_BN; f.out = e->actbuf; f.ldo = L.ld_int;
+    f.bias = L.fc1.b; f.M = M; f.tiles_n = L.fc1.rows_pad / GEMM_BN;
+    if (f8 && fused_ok_for_fp8(score_site, e->tokens)) {
+      if ((rc = launch_ln(e, x, D, L.ln2_g, L.ln2_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
+      f.A = (const bf16*)e->hbuf8; f.lda = e->ld8_dim; f.W = (const bf16*)L.fc1.w8; f.ldw = L.fc1.ld8; f.K = e->ld8_dim; f.wscale = L.fc1.wscale;
+      f.N = ld8_int; f.out = (bf16*)e->act8; f.ldo = ld8_int;      // e4m3 bytes out; the pad columns up to 128 are written (zeros)
+    } else {
+      if ((rc = launch_ln(e, x, D, L.ln2_g, L.ln2_b, e->hbuf, D, M, D))) return rc;
+      f.A = e->hbuf; f.lda = D; f.W = L.fc1.w; f.ldw = L.fc1.ld; f.K = D;
+      f.N = L.ld_int; f.out = e->actbuf; f.ldo = L.ld_int;
+    }
+    const bool f8_mlp = f.wscale != nullptr;
     f.score_site = fused ? score_site : 0; f.tokens = e->tokens; f.slab = e->slab; f.slab_ld = L.ld_int;
     f.group = rm.group; f.mpad = rm.mpad; f.n_img = n;
     f.group_m = 8;   // 8 x 8 tile patches per XCD: the 4.7 MB fc1 weight no longer thrashes the 4 MiB L2 (PMC: FETCH_SIZE / 3.7)
     // unfused pre-GELU scoring (models with < 128 tokens): the hook sees fc1's output, fc2 consumes the GELU
     // of it, so the epilogue also stores the pre-activation for the standalone L2 kernel to read.
     f.out2 = (score_site == SSP2_SCORE_PRE_GELU && !fused) ? e->prebuf : nullptr;
-    if (f.score_site == 1) rc = launch_gemm<EPI_FC1, 1>(e, f, SSP2_K_GEMM_FC1);
-    else if (f.score_site == 2) rc = launch_gemm<EPI_FC1, 2>(e, f, SSP2_K_GEMM_FC1);
-    else rc = launch_gemm<EPI_FC1, 0>(e, f, SSP2_K_GEMM_FC1);
+    if (f8_mlp) {
+      if (f.score_site == 1) rc = launch_gemm256<EPI_FC1, 1, true>(e, f, SSP2_K_GEMM_FC1);
+      else if (f.score_site == 2) rc = launch_gemm256<EPI_FC1, 2, true>(e, f, SSP2_K_GEMM_FC1);
+      else rc = launch_gemm256<EPI_FC1, 0, true>(e, f, SSP2_K_GEMM_FC1);
+    } else {
+      if (f.score_site == 1) rc = launch_gemm<EPI_FC1, 1>(e, f, SSP2_K_GEMM_FC1);
+      else if (f.score_site == 2) rc = launch_gemm<EPI_FC1, 2>(e, f, SSP2_K_GEMM_FC1);
+      else rc = launch_gemm<EPI_FC1, 0>(e, f, SSP2_K_GEMM_FC1);
+    }
     if (rc) return rc;
     if (score_site) {
       float* row = batch_scores + (size_t)l * score_ld;
@@ -565,9 +632,14 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
       }
     }
     GemmArgs o{};
-    o.A = e->actbuf; o.lda = L.ld_int; o.W = L.fc2.w; o.ldw = L.fc2.ld; o.bias = L.fc2.b;
-    o.M = M; o.N = D; o.K = L.ld_int; o.tiles_n = L.fc2.rows_pad / GEMM_BN; o.x = x; o.ldx = D;
-    if ((rc = launch_gemm<EPI_RESID>(e, o, SSP2_K_GEMM_FC2))) return rc;
+    o.bias = L.fc2.b; o.M = M; o.N = D; o.tiles_n = L.fc2.rows_pad / GEMM_BN; o.x = x; o.ldx = D;
+    if (f8_mlp) {
+      o.A = (const bf16*)e->act8; o.lda = ld8_int; o.W = (const bf16*)L.fc2.w8; o.ldw = L.fc2.ld8; o.K = ld8_int; o.wscale = L.fc2.wscale;
+      if ((rc = launch_gemm256<EPI_RESID, 0, true>(e, o, SSP2_K_GEMM_FC2))) return rc;
+    } else {
+      o.A = e->actbuf; o.lda = L.ld_int; o.W = L.fc2.w; o.ldw = L.fc2.ld; o.K = L.ld_int;
+      if ((rc = launch_gemm<EPI_RESID>(e, o, SSP2_K_GEMM_FC2))) return rc;
+    }
   }
   return 0;
 }
@@ -681,6 +753,11 @@ int ssp2_prune_ffn(ssp2_handle e, int layer, const int32_t* keep, int n_keep) {
   L.d_int = n_keep; L.ld_int = new_ld;
   L.fc1.rows = n_keep; L.fc2.cols = n_keep; L.fc2.ld = new_ld;
   e->d_int[layer] = n_keep;
+  if (e->fp8) {                                  // fresh e4m3 images (and row scales) of the compacted matrices
+    int rc;
+    if ((rc = quantise_mat(e, L.fc1)) || (rc = quantise_mat(e, L.fc2))) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
   return 0;
 }
 
@@ -902,15 +979,15 @@ static int act_l2_impl(void* stream, const void* act, int dtype, int n, RowMap r
   if (!act || !norms_ws || !out) return fail(SSP2_EINVAL, "null device pointer");
   if (n <= 0 || tokens <= 0 || d <= 0 || ld < d || (ld % 8)) return fail(SSP2_EINVAL, "bad shape n=%d tokens=%d d=%d ld=%d (ld multiple of 8, >= d)", n, tokens, d, ld);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((ld + 511) / 512, n), blk(256);
+  dim3 grid((ld + 511) / 512, n, 2), blk(256);       // z = token half (see act_l2_norms_kernel)
   if (dtype == 0)
-    hipLaunchKernelGGL(act_l2_norms_kernel<bf16>, grid, blk, 0, s, (const bf16*)act, norms_ws, rm, ld, chain);
+    hipLaunchKernelGGL(act_l2_norms_kernel<bf16>, grid, blk, 0, s, (const bf16*)act, norms_ws, rm, ld, n);
   else if (dtype == 1)
-    hipLaunchKernelGGL(act_l2_norms_kernel<float>, grid, blk, 0, s, (const float*)act, norms_ws, rm, ld, chain);
+    hipLaunchKernelGGL(act_l2_norms_kernel<float>, grid, blk, 0, s, (const float*)act, norms_ws, rm, ld, n);
   else
     return fail(SSP2_EINVAL, "dtype %d (0 = bf16, 1 = f32)", dtype);
   const int grp = (group <= 0 || group > n) ? n : group;
-  hipLaunchKernelGGL(score_colsum_kernel, dim3((ld + 255) / 256, (n + grp - 1) / grp), dim3(256), 0, s, norms_ws, out, out_stride, n, grp, ld,
+  hipLaunchKernelGGL(score_colsum_halves_kernel, dim3((ld + 63) / 64, (n + grp - 1) / grp), dim3(256), 0, s, norms_ws, out, out_stride, n, grp, ld,
                      chain);
   HIPCHK(hipGetLastError());
   return 0;

@@ -52,6 +52,10 @@ struct GemmArgs {
   // EPI_PATCH
   const float* pos; int patches;
   int group_m;                // row tiles per L2 super-tile (0 = plain N-fastest order)
+  // fp8 (e4m3) operands, gemm256 kernel with F8 = true only: A and W point at BYTES (lda / ldw / K count fp8 elements,
+  // K a multiple of 128), acc is multiplied by wscale[n] (the weight row's dequantisation scale) before the bias;
+  // EPI_FC1 then writes e4m3 bytes to `out` (ldo in bytes) for the fp8 fc2 that follows
+  const float* wscale;
 #ifdef GEMM_STAMPS
   unsigned long long* stamps; // diagnostic build only: [blocks][64] s_memtime values of wave 0
 #endif
@@ -81,6 +85,16 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 //   * gelu(x) = max(x, 0) - |x| * h  with  h = erfc(|z|)/2: one fma instead of compare + select + multiply, and one
 //     rounding less than x * (1 - h)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+// four fp32 -> four e4m3 bytes (OCP fp8, RNE), saturating at +-448 (e4m3fn has no infinity: an overflow would become NaN)
+__device__ __forceinline__ uint32_t pack_e4m3x4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
 // max(x, 0) as ONE instruction (fmaxf costs two: hipcc canonicalises the operand with v_max_f32 x, x first)
 __device__ __forceinline__ float relu_f32(float x) {
   float r;

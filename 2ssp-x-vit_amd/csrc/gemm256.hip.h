@@ -84,10 +84,18 @@ struct G256 {
 // in-lane accumulations, and every partial sum is formed in exactly the order of gemm_bf16_kernel<EPI_FC1, SCORE>
 // (a wave's 128 rows = that kernel's 128-row tile, passes h = 0, 1 = its row-waves), so the slab — and the stage-1
 // scores — are bit-identical whichever kernel a launch is routed to.
-template <int EPI, int SCORE = 0>
+// F8: both operands are e4m3 bytes (OCP fp8), 128 per 128-byte LDS row, so a K-tile carries K = 128 through the very same
+// DMA pieces, ring slots and swizzle; the matrix instruction is v_mfma_scale_f32_32x32x64_f8f6f4 with unit block
+// scales (twice the cycles of the bf16 32x32x16 form at four times the K: 2x the rate), 8 per unit instead of 16, fed by
+// the same 12 ds_read_b128; the weight row's dequantisation scale is applied in the epilogue (acc * wscale[n] + bias).
+// Which 32 of the 64 k-bytes a lane half supplies is free as long as both operands use one rule (lane half h takes
+// bytes 32h .. 32h+31 of the 64-byte step, tools/fp8_probe.hip checks the pairing on the hardware).
+template <int EPI, int SCORE = 0, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   using C = G256;
   constexpr bool SWAP = !(EPI == EPI_FC1 && SCORE != 0);
+  constexpr int ESZ = F8 ? 1 : 2;                       // bytes per operand element
+  constexpr int KT = F8 ? 128 : GEMM_BK;                // K elements per K-tile (128 bytes per LDS row either way)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -105,7 +113,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   const int lane_a = (wm * 128 + l31) * 128, lane_b = (wn * 64 + l31) * 128;
   int t16[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) t16[k] = ((2 * k + lh) ^ ((l31 >> 1) & 7)) << 4;
+  for (int k = 0; k < 4; ++k)      // bf16: k-step k takes chunk 2k + lh; fp8: step s = k >> 1 takes chunks 4s + 2lh + (k & 1)
+    t16[k] = ((F8 ? 4 * (k >> 1) + 2 * lh + (k & 1) : 2 * k + lh) ^ ((l31 >> 1) & 7)) << 4;
 
   // per-lane source of the wave's 4 LDS-DMA pieces per operand, as 32-bit BYTE offsets from g.A / g.W: the pieces are
   // issued as global_load_lds with an SGPR base (operand + K offset, scalar arithmetic) and this VGPR offset, so a
@@ -120,6 +129,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   const char* ride_base1 = nullptr;
   int m0 = 0, n0 = 0;
   float bias_next = 0.f;                                // bias[n0 + wn*64 + lane] of the tile being prefetched
+  float wsc_next = 1.f;                                 // F8: wscale[...] of the same column
   auto set_tile = [&](int tile) {
     int tm, tn;
     const int gn = g.group_m % 100, gm = g.group_m / 100;          // group_m = 100 * GM + GN (0: plain order)
@@ -145,11 +155,11 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       const int row = (wave + 8 * i) * 8 + (lane >> 3);
       const int c_src = (lane & 7) ^ ((row >> 1) & 7);
       int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
-      a_src[i] = ((uint32_t)(gr - m0) * (uint32_t)g.lda + c_src * 8) * 2;
-      w_src[i] = ((uint32_t)row * (uint32_t)g.ldw + c_src * 8) * 2;
+      a_src[i] = (uint32_t)(gr - m0) * (uint32_t)g.lda * ESZ + c_src * 16;
+      w_src[i] = (uint32_t)row * (uint32_t)g.ldw * ESZ + c_src * 16;
     }
-    a_tile = (const char*)(g.A + (size_t)m0 * g.lda);
-    w_tile = (const char*)(g.W + (size_t)n0 * g.ldw);
+    a_tile = (const char*)g.A + (size_t)m0 * g.lda * ESZ;
+    w_tile = (const char*)g.W + (size_t)n0 * g.ldw * ESZ;
   };
   auto piece_a = [&](int off, int kt, int i) { GLDS_A(a_tile + (size_t)kt * (GEMM_BK * 2) + a_src[i], smem + off + (wave + 8 * i) * 1024); };
   auto piece_b = [&](int off, int kt, int i) { glds16(w_tile + (size_t)kt * (GEMM_BK * 2) + w_src[i], smem + off + (wave + 8 * i) * 1024); };
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     for (int i = 0; i < 4; ++i) piece_b(off, kt, i);
   };
 
-  const int nk = g.K / GEMM_BK;
+  const int nk = g.K / KT;
   int tile = wg;
 #ifdef GEMM_STAGGER
   // experiment: every second workgroup of an XCD starts g.group_m x 1024 cycles late, so that the residual epilogues'
@@ -173,6 +183,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   if (tile < ntiles) {
     set_tile(tile);
     bias_next = g.bias[n0 + wn * 64 + lane];
+    if (F8) wsc_next = g.wscale[n0 + wn * 64 + lane];
     stage_b(C::B0, 0);
     stage_a(C::A0, 0);
     if (nk > 1) stage_a(C::A1, 1);
@@ -210,6 +221,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     // B(kt-1) / A(kt-1).  At the end of phase 4kt+3 the 4 youngest DMAs of every wave are its A(kt+2) pieces: the
     // counted wait retires its B(kt+1) and A(kt+1) pieces one barrier before their first read (phase 4kt+4).
     bf16x8 fa[2][C::TM], fb[2][C::TN];
+    i32x8 ga[C::TM], gb[C::TN];                                // F8: one 64-deep step per unit, 32 bytes per lane and fragment
     int sa = C::A0, sb = C::B0;
     uint32_t ride0[4], ride1[4];                               // the pieces carried in half 0 / half 1 (selected once per tile)
 #pragma unroll
@@ -250,6 +262,19 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         {
           const char* As = smem + sa + lane_a;
           const char* Bs = smem + sb + lane_b;
+          if constexpr (F8) {
+            const int o0 = t16[2 * half], o1 = t16[2 * half + 1];
+#pragma unroll
+            for (int i = 0; i < C::TN; ++i) {
+              const i32x4 lo = *(const i32x4*)(Bs + o0 + i * 4096), hi = *(const i32x4*)(Bs + o1 + i * 4096);
+              gb[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) {
+              const i32x4 lo = *(const i32x4*)(As + o0 + i * 4096), hi = *(const i32x4*)(As + o1 + i * 4096);
+              ga[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+          } else {
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             const int o = t16[2 * half + s2];
@@ -257,6 +282,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             for (int i = 0; i < C::TN; ++i) fb[s2][i] = *(const bf16x8*)(Bs + o + i * 4096);
 #pragma unroll
             for (int i = 0; i < C::TM; ++i) fa[s2][i] = *(const bf16x8*)(As + o + i * 4096);
+          }
           }
         }
         if (PP_NL > 0 && dma_on && early_ok) {
@@ -276,6 +302,27 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         if (half == 0 && kt < 6) TSTAMP(4 + 6 * kt);
         // ---------------- COMPUTE (+ the remaining DMA pieces behind MFMA pairs 0, 2, 4, 6)
+        if constexpr (F8) {
+#pragma unroll
+          for (int a = 0; a < C::TM; ++a) {       // 8 MFMAs of 64 cycles; a piece behind every second one (= the bf16 cadence)
+#pragma unroll
+            for (int b = 0; b < C::TN; ++b)
+              acc[a][b] = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(gb[b], ga[a], acc[a][b], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f)
+                               : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ga[a], gb[b], acc[a][b], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            __builtin_amdgcn_sched_barrier(0);
+            if (dma_on && !(PP_NL > 0 && early_ok && a < PP_NL)) piece(a);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // Pin the accumulators HERE: the scaled MFMA is a register-only instruction without side effects, and without an
+          // ordered use hipcc's machine sinking moved this unit's eight MFMAs down behind the next barrier pair, next to
+          // the following unit's (16 MFMAs in one phase, the partner idle, both units' fragments live: 68 spilled VGPRs
+          // whose scratch reloads sat in front of the LDS-DMA issues with a vmcnt(0) each).  An empty volatile asm that
+          // reads and writes each accumulator keeps the producers above it; volatile asms keep their order with the barriers.
+#pragma unroll
+          for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+            for (int b = 0; b < C::TN; ++b) asm volatile("" : "+v"(acc[a][b]));
+        } else
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -319,10 +366,13 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     // compiler's wait for the (long finished) bias load cannot land behind them and drain them
     float bias_lane = bias_next;
     asm volatile("v_mov_b32 %0, %0" : "+v"(bias_lane));
+    float wsc_lane = wsc_next;
+    if (F8) asm volatile("v_mov_b32 %0, %0" : "+v"(wsc_lane));
     const int next = tile + G;
     if (next < ntiles) {
       set_tile(next);
       bias_next = g.bias[n0 + wn * 64 + lane];
+      if (F8) wsc_next = g.wscale[n0 + wn * 64 + lane];
       stage_b(C::B0, 0);
       stage_a(C::A0, 0);
       if (nk > 1) stage_a(C::A1, 1);
@@ -341,6 +391,20 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bb[b][q][r] = __shfl(bias_lane, b * 32 + 8 * q + 4 * lhe + r);
+    float sc[2][4][4];                                 // F8: the columns' dequantisation scales, same lane -> column map
+    if constexpr (F8 && SWAP) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[b][q][r] = __shfl(wsc_lane, b * 32 + 8 * q + 4 * lhe + r);
+    }
+    // pre-activation of element (a, b, 4q + r) before the bf16 rounding: acc + bias, or acc * wscale + bias on fp8 operands
+    auto pre_f32 = [&](int a, int b, int q, int r) -> float {
+      if constexpr (F8) return fmaf(acc[a][b][4 * q + r], sc[b][q][r], bb[b][q][r]);
+      else return acc[a][b][4 * q + r] + bb[b][q][r];
+    };
     char* const stg = smem + C::STG + wave * 8192;     // wave-private
     counted = full && SWAP;
     // g0 is one barrier short of g1 (the skew): it pays it here, a few hundred cycles into its epilogue, while g1
@@ -351,6 +415,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       // ---- fc1 + GELU + stage-1 score, plain layout: acc[a][b][i]: row = row0 + a*32 + (i&3) + 8*(i>>2) + 4*lh,
       // column = col0 + b*32 + l31.  Same arithmetic, in the same order, as gemm_bf16_kernel<EPI_FC1, SCORE>.
       const float bias2[2] = {__shfl(bias_lane, l31e), __shfl(bias_lane, 32 + l31e)};
+      const float scale2[2] = {F8 ? __shfl(wsc_lane, l31e) : 1.f, F8 ? __shfl(wsc_lane, 32 + l31e) : 1.f};
       const int m128 = row0;                           // this wave's 128-row tile (= one tile of the 128x128 kernel); m0 already names the NEXT tile
       int bnd = 1 << 30, row_lim = g.M - m128;         // rows of the tile at or past row_lim never count
       {
@@ -369,7 +434,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const float bias = bias2[b];
-          char* const stc = stg + (b * 32 + l31e) * 2;
+          const float scl = scale2[b];
+          char* const stc = stg + (b * 32 + l31e) * (F8 ? 1 : 2);
 #pragma unroll
           for (int a2 = 0; a2 < 2; ++a2) {
             const int a = 2 * h + a2;
@@ -379,7 +445,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
               const int rw = a2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * lhe;     // row inside the 64-row pass (i even: rw, rw+1)
-              const uint32_t pk = pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias);
+              const uint32_t pk = F8 ? pack_bf16x2(fmaf(acc[a][b][i], scl, bias), fmaf(acc[a][b][i + 1], scl, bias))
+                                     : pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias);
               f32x2 pre;
               const f32x2 gl = gelu_erf_pk(pk, pre);
               const uint32_t o = pack_bf16x2(gl.x, gl.y);
@@ -393,21 +460,37 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
                 if (r0 < bnd) s0 += q0; else s1 += q0;
                 if (r0 + 1 < bnd) s0 += q1; else s1 += q1;
               }
-              const bf16x2 ov = __builtin_bit_cast(bf16x2, o);
-              *(bf16*)(stc + rw * 128) = ov[0];
-              *(bf16*)(stc + (rw + 1) * 128) = ov[1];
+              if constexpr (F8) {                         // e4m3 bytes of the bf16 activation, 64-byte staging rows
+                const uint32_t e = pack_e4m3x4(bf16lo_f32(o), bf16hi_f32(o), 0.f, 0.f);
+                *(uint8_t*)(stc + rw * 64) = (uint8_t)e;
+                *(uint8_t*)(stc + (rw + 1) * 64) = (uint8_t)(e >> 8);
+              } else {
+                const bf16x2 ov = __builtin_bit_cast(bf16x2, o);
+                *(bf16*)(stc + rw * 128) = ov[0];
+                *(bf16*)(stc + (rw + 1) * 128) = ov[1];
+              }
             }
             if (plain && rb >= bnd) { ssq[h][1][b] += s0; } else { ssq[h][0][b] += s0; ssq[h][1][b] += s1; }
           }
         }
         WAITL0();
         if (wave_cols_ok) {
+          if constexpr (F8) {                             // 64 rows x 64 bytes: 4 sixteen-byte chunks per row
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int r = it * 16 + (le >> 2), c = (le & 3) * 16;
+              const i32x4 v = *(const i32x4*)(stg + r * 64 + c);
+              const int m = row0 + h * 64 + r;
+              if (m < g.M) *(i32x4*)((char*)g.out + (size_t)m * g.ldo + col0 + c) = v;
+            }
+          } else {
 #pragma unroll
           for (int it = 0; it < 8; ++it) {
             const int r = it * 8 + (le >> 3), c = (le & 7) * 8;
             const bf16x8 v = *(const bf16x8*)(stg + r * 128 + c * 2);
             const int m = row0 + h * 64 + r;
             if (m < g.M) *(bf16x8*)(g.out + (size_t)m * g.ldo + col0 + c) = v;
+          }
           }
         }
         WAITL0();
@@ -423,6 +506,48 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
           const int col = col0 + b * 32 + l31e;
           if (lhe == 0 && col < g.slab_ld) g.slab[((size_t)(m128 >> 7) * 2 + sgm) * g.slab_ld + col] = t0 + t1;
         }
+    } else
+    if (EPI == EPI_FC1 && F8) {   // fc1 on fp8 operands: bias + erf-GELU on the bf16 pre-activation, e4m3 bytes out (for the fp8 fc2)
+      // two passes of 64 rows x 64 bytes (4 KiB): a lane's 4 consecutive columns are one dword; 16-byte chunk c of row r sits
+      // at chunk c ^ ((r >> 1) & 3)
+      if (wave_cols_ok) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int a = 2 * h + a2;
+                float gv[4];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                  const uint32_t pk = pack_bf16x2(pre_f32(a, b, q, 2 * p), pre_f32(a, b, q, 2 * p + 1));
+                  f32x2 pre;
+                  const f32x2 gl = gelu_erf_pk(pk, pre);
+                  const uint32_t o = pack_bf16x2(gl.x, gl.y);
+                  gv[2 * p] = bf16lo_f32(o); gv[2 * p + 1] = bf16hi_f32(o);
+                }
+                const int r = a2 * 32 + l31e, chunk = 2 * b + (q >> 1);
+                *(uint32_t*)(stg + r * 64 + ((chunk ^ ((r >> 1) & 3)) << 4) + 8 * (q & 1) + 4 * lhe) = pack_e4m3x4(gv[0], gv[1], gv[2], gv[3]);
+              }
+          WAITL0();
+          i32x4 v[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int r = it * 16 + (le >> 2), c = le & 3;
+            v[it] = *(const i32x4*)(stg + r * 64 + ((c ^ ((r >> 1) & 3)) << 4));
+          }
+          WAITL0();
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int r = it * 16 + (le >> 2), c = le & 3;
+            const int m = row0 + h * 64 + r;
+            if (m < g.M) *(i32x4*)((char*)g.out + (size_t)m * g.ldo + col0 + c * 16) = v[it];
+          }
+        }
+      }
     } else
     if (EPI == EPI_BF16 || EPI == EPI_FC1) {   // EPI_FC1 here = bias + erf-GELU, no scoring (evaluation passes)
       // two passes of 64 rows x 64 columns bf16 (8 KiB): 16-byte chunk c of row r sits at chunk c ^ (r & 7)
@@ -442,7 +567,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
                 uint32_t pk[2];
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                  pk[p] = pack_bf16x2(acc[a][b][4 * q + 2 * p] + bb[b][q][2 * p], acc[a][b][4 * q + 2 * p + 1] + bb[b][q][2 * p + 1]);
+                  pk[p] = pack_bf16x2(pre_f32(a, b, q, 2 * p), pre_f32(a, b, q, 2 * p + 1));
                   if (EPI == EPI_FC1) {
                     f32x2 pre;
                     const f32x2 gl = gelu_erf_pk(pk[p], pre);
@@ -487,8 +612,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
           for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const uint32_t p0 = pack_bf16x2(acc[a][b][4 * q] + bb[b][q][0], acc[a][b][4 * q + 1] + bb[b][q][1]);
-              const uint32_t p1 = pack_bf16x2(acc[a][b][4 * q + 2] + bb[b][q][2], acc[a][b][4 * q + 3] + bb[b][q][3]);
+              const uint32_t p0 = pack_bf16x2(pre_f32(a, b, q, 0), pre_f32(a, b, q, 1));
+              const uint32_t p1 = pack_bf16x2(pre_f32(a, b, q, 2), pre_f32(a, b, q, 3));
               acc[a][b][4 * q] = bf16lo_f32(p0); acc[a][b][4 * q + 1] = bf16hi_f32(p0);
               acc[a][b][4 * q + 2] = bf16lo_f32(p1); acc[a][b][4 * q + 3] = bf16hi_f32(p1);
             }

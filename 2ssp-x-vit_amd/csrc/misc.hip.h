@@ -43,6 +43,15 @@ __global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ 
   }
 }
 
+// four fp32 -> four e4m3 bytes, saturating (same arithmetic as gemm.hip.h pack_e4m3x4; this header is included first)
+__device__ __forceinline__ uint32_t pack_e4m3x4_from(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: fp32 rows -> bf16 rows.  One wave per row, the row lives in registers
 // (two-pass mean / variance in fp32), 16-byte loads and 8-byte stores (lane owns float4 chunks lane, lane+64, ..).
@@ -52,7 +61,8 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, size_t in_stride,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16* __restrict__ y,
-                                                            int out_ld, int rows, int D, float eps, RowMap gather) {
+                                                            int out_ld, int rows, int D, float eps, RowMap gather,
+                                                            uint8_t* __restrict__ y8 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -78,6 +88,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
   bf16* yr = y + (size_t)row * out_ld;
+  uint8_t* yr8 = y8 ? y8 + (size_t)row * out_ld : nullptr;   // fp8 mode: e4m3 bytes (of the bf16-rounded value), out_ld in bytes
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = i * 64 + lane;
@@ -86,7 +97,8 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
       bf16x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = (bf16)((v[i][k] - mean) * rstd * g4[k] + b4[k]);
-      *(bf16x4*)(yr + c * 4) = o;
+      if (yr8) *(uint32_t*)(yr8 + c * 4) = pack_e4m3x4_from((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+      else *(bf16x4*)(yr + c * 4) = o;
     }
   }
 }
@@ -158,23 +170,29 @@ __device__ __forceinline__ void load8<float>(const float* p, float (&f)[8]) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__ act, float* __restrict__ norms,
-                                                          RowMap rm, int ld, int chain) {
+__global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__ act, float* __restrict__ ssq_ws,
+                                                          RowMap rm, int ld, int n) {
+  // grid (ld/512, n, 2): blockIdx.z = token half.  One (sample, 512-column chunk) per block gave 6 x 64 = 384 blocks for
+  // a B/16 calibration batch — 1.5 per CU, so half the chip idled through the second round; with the tokens cut in two
+  // it is 768 = 3 per CU.  The halves' sums of squares go to ssq_ws[half][s][j]; score_colsum_kernel adds them
+  // (first half + second half: a fixed association), takes the root and sums the samples in order.
   const int tokens = rm.tokens;
   __shared__ float red[4][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = blockIdx.y;
   const int col = blockIdx.x * 512 + lane * 8;
   const bool ok = col < ld;
+  const int mid = (tokens + 1) >> 1;
+  const int t_begin = blockIdx.z ? mid : 0, t_end = blockIdx.z ? tokens : mid;
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
   if (ok) {
     const T* base = act + (size_t)row_of(rm, s) * ld + col;
-    int t = wave;
-    // 16 token rows in flight per wave (16 KiB; ~6 waves per CU => ~96 KiB per CU outstanding): with 4 rows the loop was
-    // latency-bound (13 round trips of ~1.2 us per wave = the whole 16 us of the launch), now 3 round trips + a tail
-    for (; t + 60 < tokens; t += 64) {
+    int t = t_begin + wave;
+    // 16 token rows in flight per wave (16 KiB; 12 waves per CU => ~190 KiB per CU outstanding): with 4 rows the loop
+    // was latency-bound (13 round trips of ~1.2 us per wave = the whole 16 us of the launch)
+    for (; t + 60 < t_end; t += 64) {
       float f[16][8];
 #pragma unroll
       for (int r = 0; r < 16; ++r) load8<T>(base + (size_t)(t + 4 * r) * ld, f[r]);
@@ -183,7 +201,16 @@ __global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] += f[r][k] * f[r][k] + f[r + 1][k] * f[r + 1][k] + f[r + 2][k] * f[r + 2][k] + f[r + 3][k] * f[r + 3][k];
     }
-    for (; t + 12 < tokens; t += 16) {
+    for (; t + 28 < t_end; t += 32) {
+      float f[8][8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) load8<T>(base + (size_t)(t + 4 * r) * ld, f[r]);
+#pragma unroll
+      for (int r = 0; r < 8; r += 4)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += f[r][k] * f[r][k] + f[r + 1][k] * f[r + 1][k] + f[r + 2][k] * f[r + 2][k] + f[r + 3][k] * f[r + 3][k];
+    }
+    for (; t + 12 < t_end; t += 16) {
       float f0[8], f1[8], f2[8], f3[8];
       load8<T>(base + (size_t)t * ld, f0);
       load8<T>(base + (size_t)(t + 4) * ld, f1);
@@ -192,7 +219,7 @@ __global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += f0[k] * f0[k] + f1[k] * f1[k] + f2[k] * f2[k] + f3[k] * f3[k];
     }
-    for (; t < tokens; t += 4) {
+    for (; t < t_end; t += 4) {
       float f0[8];
       load8<T>(base + (size_t)t * ld, f0);
 #pragma unroll
@@ -203,11 +230,43 @@ __global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__
   for (int k = 0; k < 8; ++k) red[wave][lane * 8 + k] = acc[k];
   __syncthreads();
   for (int c = threadIdx.x; c < 512; c += 256) {
-    if (blockIdx.x * 512 + c < ld) {
-      float nrm = sqrtf((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
-      if (chain) nrm = bf16_round(nrm);
-      norms[(size_t)s * ld + blockIdx.x * 512 + c] = nrm;
+    if (blockIdx.x * 512 + c < ld)
+      ssq_ws[((size_t)blockIdx.z * n + s) * ld + blockIdx.x * 512 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  }
+}
+
+// step 2 of the standalone path: out[g][j] = sum over the samples s of group g, in index order, of
+// sqrt(ssq[0][s][j] + ssq[1][s][j]) (bf16-rounded per sample and per group sum on the reference chain).
+__global__ __launch_bounds__(256) void score_colsum_halves_kernel(const float* __restrict__ ssq_ws, float* __restrict__ out, size_t out_stride, int n,
+                                                                   int group, int ld, int chain) {
+  // grid (ld/64, groups); 256 threads = 64 columns x 4 sample lanes: lane q adds samples s0+q, s0+q+4, ... of the group in
+  // that order, the four partial sums are folded as (p0 + p1) + (p2 + p3) — a fixed association that depends only on the
+  // group's own samples, so the result does not depend on what else shares the launch.  (One thread per column walked
+  // the 64 samples alone: 7.5 us on 12 blocks for a B/16 batch.)
+  __shared__ float part[4][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  const int s0 = blockIdx.y * group;
+  const int s1 = min(n, s0 + group);
+  const float* h0 = ssq_ws;
+  const float* h1 = ssq_ws + (size_t)n * ld;
+  float acc = 0.f;
+  if (j < ld) {
+    int s = s0 + q;
+    for (; s + 28 < s1; s += 32) {          // 8 samples (16 loads) in flight
+      float a[8], b[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a[k] = h0[(size_t)(s + 4 * k) * ld + j]; b[k] = h1[(size_t)(s + 4 * k) * ld + j]; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { float nrm = sqrtf(a[k] + b[k]); if (chain) nrm = bf16_round(nrm); acc += nrm; }
     }
+    for (; s < s1; s += 4) { float nrm = sqrtf(h0[(size_t)s * ld + j] + h1[(size_t)s * ld + j]); if (chain) nrm = bf16_round(nrm); acc += nrm; }
+  }
+  part[q][c] = acc;
+  __syncthreads();
+  if (q == 0 && j < ld) {
+    const float t = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    out[(size_t)blockIdx.y * out_stride + j] = chain ? bf16_round(t) : t;
   }
 }
 
@@ -281,4 +340,28 @@ __global__ void convert_pad_bf16_kernel(const float* __restrict__ src, bf16* __r
 __global__ void round_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int n_pad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_pad) dst[i] = i < n ? bf16_round(src[i]) : 0.f;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// fp8 weight image: bf16 [rows_pad, ld] -> e4m3 bytes [rows_pad, ld8] with one dequantisation scale per row
+// (scale = amax / 448, the e4m3 maximum; 1 for an all-zero row), zero padded.  One wave per row.
+__global__ __launch_bounds__(256) void quant_rows_e4m3_kernel(const bf16* __restrict__ w, int ld, uint8_t* __restrict__ w8, int ld8,
+                                                             float* __restrict__ scale, int rows, int cols, int rows_pad) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows_pad) return;
+  float amax = 0.f;
+  if (row < rows)
+    for (int c = lane; c < cols; c += 64) amax = fmaxf(amax, fabsf((float)w[(size_t)row * ld + c]));
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax / 448.f : 1.f;
+  const float inv = 1.f / sc;
+  for (int c4 = lane; c4 < ld8 / 4; c4 += 64) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int c = c4 * 4 + k; v[k] = (row < rows && c < cols) ? (float)w[(size_t)row * ld + c] * inv : 0.f; }
+    *(uint32_t*)(w8 + (size_t)row * ld8 + c4 * 4) = pack_e4m3x4_from(v[0], v[1], v[2], v[3]);
+  }
+  if (lane == 0) scale[row] = sc;
 }

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <vector>
 #include "../gemm256.hip.h"
@@ -13,6 +14,23 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+static float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+// OCP e4m3fn: decode exactly, encode by nearest (ties to even mantissa) over the 256 codes, saturating at +-448
+static float e4m3_to_f(uint8_t v) {
+  const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+  float f = e == 0 ? ldexpf((float)m, -9) : ldexpf(1.f + m / 8.f, e - 7);
+  return s ? -f : f;
+}
+static uint8_t f_to_e4m3(float f) {
+  static float tab[127]; static bool init = false;
+  if (!init) { for (int i = 0; i < 127; ++i) tab[i] = e4m3_to_f((uint8_t)i); init = true; }      // 0 .. 0x7e = 448 (0x7f = NaN)
+  const float a = fabsf(f) > 448.f ? 448.f : fabsf(f);
+  int lo = 0, hi = 126;
+  while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (tab[mid] <= a) lo = mid; else hi = mid; }
+  int best = lo;
+  if (hi != lo) { const float dl = a - tab[lo], dh = tab[hi] - a; best = dh < dl ? hi : (dl < dh ? lo : ((lo & 1) ? hi : lo)); }
+  return (uint8_t)(best | (f < 0 ? 0x80 : 0));
+}
 
 template <int EPI, int SCORE = 0> static void launch(const GemmArgs& g, hipStream_t s) {
   static bool done = false;
@@ -27,6 +45,12 @@ template <int EPI, int SCORE = 0> static void launch256(GemmArgs g, hipStream_t 
   g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
   hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(512), G256::LDS, s, g);
 }
+template <int EPI, int SCORE = 0> static void launch256f8(GemmArgs g, hipStream_t s) {   // e4m3 operands (gemm256 with F8 = true)
+  static bool done = false;
+  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS)); done = true; }
+  g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE, true>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(512), G256::LDS, s, g);
+}
 template <int EPI, int NW> static void launch256v1(GemmArgs g, hipStream_t s) {   // round-1 kernel, A/B reference
   static bool done = false;
   if (!done) { CK(hipFuncSetAttribute((const void*)gemm256v1_bf16_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, G256v1<NW>::LDS)); done = true; }
@@ -34,8 +58,72 @@ template <int EPI, int NW> static void launch256v1(GemmArgs g, hipStream_t s) { 
   hipLaunchKernelGGL((gemm256v1_bf16_kernel<EPI, NW>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(NW * 64), G256v1<NW>::LDS, s, g);
 }
 
+// epi 30 bf16-out (QKV), 31 resid (fc2), 32 fc1 (+GELU, e4m3 out), 33 fc1 + pre-GELU score (e4m3 out + slab): e4m3 operands.
+// Operands are quantised on the host (A: direct cast, W: per-row scale amax/448), the reference is the fp32 sum of the
+// exact products of the DEQUANTISED values, so the check isolates the kernel (layout, scale, epilogue) from quantisation.
+static int run_fp8(int M, int N, int K, int epi, int iters, int tokens) {
+  const int Npad = (N + 255) / 256 * 256, K8 = (K + 127) / 128 * 128;
+  std::vector<uint8_t> hA((size_t)M * K8, 0), hW((size_t)Npad * K8, 0);
+  std::vector<float> fA((size_t)M * K8, 0.f), fW((size_t)Npad * K8, 0.f), hs(Npad, 1.f), hb(Npad, 0.f);
+  srand(2);
+  for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) { const uint8_t q = f_to_e4m3(((rand() / (float)RAND_MAX) * 2.f - 1.f) * 3.f); hA[(size_t)m * K8 + k] = q; fA[(size_t)m * K8 + k] = e4m3_to_f(q); }
+  for (int n = 0; n < N; ++n) {
+    std::vector<float> row(K); float amax = 0.f;
+    for (int k = 0; k < K; ++k) { row[k] = ((rand() / (float)RAND_MAX) * 2.f - 1.f) * 0.05f * (1 + n % 7); amax = std::max(amax, fabsf(row[k])); }
+    const float sc = amax / 448.f; hs[n] = sc;
+    for (int k = 0; k < K; ++k) { const uint8_t q = f_to_e4m3(row[k] / sc); hW[(size_t)n * K8 + k] = q; fW[(size_t)n * K8 + k] = e4m3_to_f(q); }
+    hb[n] = bf2f(f2bf(0.01f * (n % 13 - 6)));
+  }
+  uint8_t *A, *W, *out8; bf16* out; float *bias, *ws, *x, *slab;
+  CK(hipMalloc(&A, hA.size())); CK(hipMalloc(&W, hW.size())); CK(hipMalloc(&out, (size_t)M * Npad * 2)); CK(hipMalloc(&out8, (size_t)M * Npad));
+  CK(hipMalloc(&bias, Npad * 4)); CK(hipMalloc(&ws, Npad * 4)); CK(hipMalloc(&x, (size_t)(M + 4) * Npad * 4)); CK(hipMalloc(&slab, (size_t)((M + 127) / 128) * 2 * Npad * 4));
+  CK(hipMemcpy(A, hA.data(), hA.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(W, hW.data(), hW.size(), hipMemcpyHostToDevice));
+  CK(hipMemcpy(bias, hb.data(), Npad * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ws, hs.data(), Npad * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(x, 0, (size_t)(M + 4) * Npad * 4)); CK(hipMemset(out, 0, (size_t)M * Npad * 2)); CK(hipMemset(out8, 0, (size_t)M * Npad)); CK(hipMemset(slab, 0, (size_t)((M + 127) / 128) * 2 * Npad * 4));
+  GemmArgs g{};
+  g.A = (const bf16*)A; g.lda = K8; g.W = (const bf16*)W; g.ldw = K8; g.bias = bias; g.wscale = ws; g.M = M; g.N = N; g.K = K8;
+  g.out = epi >= 32 ? (bf16*)out8 : out; g.ldo = Npad; g.x = x; g.ldx = Npad; g.tokens = tokens; g.slab = slab; g.slab_ld = Npad;
+  g.score_site = epi == 33 ? 1 : 0;
+  hipStream_t s; CK(hipStreamCreate(&s));
+  auto run = [&]() { switch (epi) { case 30: launch256f8<EPI_BF16>(g, s); break; case 31: launch256f8<EPI_RESID>(g, s); break;
+                                    case 32: launch256f8<EPI_FC1, 0>(g, s); break; case 33: launch256f8<EPI_FC1, 1>(g, s); break; } };
+  run(); CK(hipStreamSynchronize(s));
+  // reference on a sample of rows (all columns): full check is M*N*K host flops
+  std::vector<uint16_t> ho((size_t)M * Npad); std::vector<uint8_t> ho8((size_t)M * Npad); std::vector<float> hx((size_t)(M + 4) * Npad);
+  CK(hipMemcpy(ho.data(), out, ho.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(ho8.data(), out8, ho8.size(), hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hx.data(), x, hx.size() * 4, hipMemcpyDeviceToHost));
+  size_t bad = 0, checked = 0; double maxrel = 0;
+  const int step = std::max(1, M / 97);
+  for (int m = 0; m < M; m += (m < 300 || m > M - 300) ? 1 : step)
+    for (int n = 0; n < N; ++n) {
+      double acc = 0, mag = 0;
+      for (int k = 0; k < K; ++k) { const double t = (double)fA[(size_t)m * K8 + k] * fW[(size_t)n * K8 + k]; acc += t; mag += fabs(t); }
+      const float pre = bf2f(f2bf((float)(acc * hs[n]) + hb[n]));
+      const float sumtol = (float)(2e-6 * mag * hs[n]);          // fp32 summation-order error where the terms cancel
+      ++checked;
+      if (epi == 30) { const float got = bf2f(ho[(size_t)m * Npad + n]); const float d = fabsf(got - pre); const float tol = fabsf(pre) * 0.0079f + sumtol + 1e-6f; if (d > tol) { if (bad < 8) printf("  out[%d][%d] = %g, ref %g\n", m, n, got, pre); ++bad; } maxrel = std::max(maxrel, (double)d / (fabsf(pre) + 1e-3)); }
+      else if (epi == 31) { const float got = hx[(size_t)m * Npad + n]; const float d = fabsf(got - pre); const float tol = fabsf(pre) * 0.0079f + sumtol + 1e-6f; if (d > tol) { if (bad < 8) printf("  x[%d][%d] = %g, ref %g\n", m, n, got, pre); ++bad; } maxrel = std::max(maxrel, (double)d / (fabsf(pre) + 1e-3)); }
+      else { const float ge = bf2f(f2bf(0.5f * pre * (1.f + erff(pre * 0.70710678f)))); const float got = e4m3_to_f(ho8[(size_t)m * Npad + n]);
+             const float d = fabsf(got - ge); const float tol = fabsf(ge) * 0.13f + 0.004f; if (d > tol) { if (bad < 8) printf("  act8[%d][%d] = %g, ref gelu %g (pre %g)\n", m, n, got, ge, pre); ++bad; } }
+    }
+  if (epi == 31) { for (size_t i = (size_t)M * Npad; i < hx.size(); ++i) if (hx[i] != 0.f) { ++bad; } }
+  printf("fp8 epi %d  M=%d N=%d K=%d: %zu of %zu checked elements outside tolerance%s  (max rel err %.3g)\n", epi, M, N, K, bad, checked, bad ? "  <-- FAIL" : " (ok)", maxrel);
+  for (int i = 0; i < 3; ++i) run();
+  CK(hipStreamSynchronize(s));
+  std::vector<float> ms(iters);
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < iters; ++i) { CK(hipEventRecord(a, s)); run(); CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms[i], a, b)); }
+  std::sort(ms.begin(), ms.end());
+  const double fl = 2.0 * M * (double)N * K;
+  printf("M=%d N=%d K=%d epi=%d (fp8)  median %.1f us  min %.1f us  -> %.0f TFLOP/s (median) %.0f (min)\n", M, N, K, epi, ms[iters / 2] * 1e3, ms[0] * 1e3,
+         fl / (ms[iters / 2] * 1e-3) / 1e12, fl / (ms[0] * 1e-3) / 1e12);
+  return bad ? 2 : 0;
+}
+
 int main(int argc, char** argv) {
   { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); nCU = pr.multiProcessorCount; }
+  if (argc > 4 && atoi(argv[4]) >= 30 && atoi(argv[4]) <= 33)
+    return run_fp8(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 20, argc > 6 ? atoi(argv[6]) : 197);
   int M = argc > 1 ? atoi(argv[1]) : 12608, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
   int epi = argc > 4 ? atoi(argv[4]) : 2, iters = argc > 5 ? atoi(argv[5]) : 20, tokens = argc > 6 ? atoi(argv[6]) : 197;
   int Npad = (N + 255) / 256 * 256;

@@ -68,7 +68,7 @@ at::Tensor act_l2_accum(const at::Tensor& act, int64_t score_chain) {
   TORCH_CHECK(act.is_cuda() && act.dim() == 3 && act.is_contiguous(), "ssp2vit: act must be a contiguous [n, tokens, d] device tensor");
   TORCH_CHECK(act.scalar_type() == at::kBFloat16 || act.scalar_type() == at::kFloat, "ssp2vit: act must be bf16 or f32");
   const int n = (int)act.size(0), t = (int)act.size(1), d = (int)act.size(2);
-  at::Tensor ws = at::empty({n, d}, act.options().dtype(at::kFloat));
+  at::Tensor ws = at::empty({2, n, d}, act.options().dtype(at::kFloat));
   at::Tensor out = at::empty({d}, act.options().dtype(at::kFloat));
   check(ssp2_act_l2_accum(stream_of(act), act.data_ptr(), act.scalar_type() == at::kFloat ? 1 : 0, n, t, d, d, (int)score_chain, 0,
                           ws.data_ptr<float>(), out.data_ptr<float>(), (size_t)d), "act_l2_accum");

@@ -54,6 +54,9 @@ class VitEngine:
             self.tokens = self.lib.ssp2_tokens(self.h)
             if _twin_of is None:
                 self._load(weights)
+                if precision == "fp8":
+                    self._bind_stream()
+                    check(self.lib.ssp2_set_precision(self.h, 1))
             else:
                 self._bind_stream()
                 check(self.lib.ssp2_clone_weights(self.h, _twin_of.h))
@@ -223,7 +226,7 @@ class VitEngine:
             raise ValueError("act must be a contiguous [n, tokens, d] device tensor")
         n, t, d = act.shape
         dtype = {torch.bfloat16: 0, torch.float32: 1}[act.dtype]
-        ws = torch.empty(n, d, dtype=torch.float32, device=act.device)
+        ws = torch.empty(2, n, d, dtype=torch.float32, device=act.device)
         out = torch.empty(d, dtype=torch.float32, device=act.device)
         check(self.lib.ssp2_act_l2_accum(C.c_void_p(torch.cuda.current_stream(act.device).cuda_stream), _ptr(act), dtype,
                                          n, t, d, d, SCORE_CHAIN[score_chain], 0, _ptr(ws), _ptr(out), d))

@@ -82,6 +82,16 @@ int ssp2_load_tensor(ssp2_handle h, int kind, int layer, const float* host, size
  * this point. */
 int ssp2_load_tensor_dev(ssp2_handle h, int kind, int layer, const float* dev_ptr, size_t numel);
 
+/* Arithmetic of the three large projections (QKV, fc1, fc2) of launches with >= 4096 token rows.
+ *   SSP2_PREC_BF16  (default) bf16 operands — the reference's CPU-autocast arithmetic, the parity mode.
+ *   SSP2_PREC_FP8   opt-in, BASELINE.json configs[4]: OCP e4m3 operands on the CDNA4 scaled-MFMA path (2x the bf16 matrix
+ *                   rate): weights quantised per output row (scale = amax / 448) from their bf16 image, activations cast
+ *                   directly (LayerNorm output and GELU output are O(1)), fp32 accumulation, scale applied before the bias.
+ *                   The reference has no fp8 arithmetic: this mode is checked by tolerance against the bf16 engine.
+ * Call after the weights are loaded; synchronous with respect to later launches on the handle's stream. */
+enum { SSP2_PREC_BF16 = 0, SSP2_PREC_FP8 = 1 };
+int ssp2_set_precision(ssp2_handle h, int mode);
+
 /* Row layout of the token matrix x.  group <= 0 or >= n: images contiguous, ssp2_rows = n*N.  0 < group < n: SLABS of
  * `group` images (one dataloader batch each), every slab padded to a multiple of 256 rows — a sample then sits at the
  * same offset inside its slab whichever call it is part of, so per-tile partial sums (hence stage-1 scores) do not
@@ -144,7 +154,7 @@ int ssp2_prune_ffn_into(ssp2_handle dst, ssp2_handle src, int layer, const int32
 /* a2 standalone (the hook body on an activation tensor that already sits in HBM):
  *   act_dev bf16 (dtype 0) or f32 (dtype 1), [n, tokens, ld] with the first d columns used;
  *   out_dev f32 [ceil(n/group), out_stride] : out[g][j] = sum_{s in group g} sqrt(sum_t act[s,t,j]^2)
- *   (group <= 0: one group of n); norms_ws_dev f32 [n, ld] scratch.
+ *   (group <= 0: one group of n); norms_ws_dev f32 [2, n, ld] scratch (sums of squares of the two token halves).
  * HBM-bound: n*tokens*d*sizeof(act) bytes read once. */
 int ssp2_act_l2_accum(void* hip_stream, const void* act_dev, int dtype, int n, int tokens, int d, int ld,
                       int score_chain, int group, float* norms_ws_dev, float* out_dev, size_t out_stride);

@@ -18,7 +18,7 @@ acc = collections.defaultdict(lambda: [0.0, 0, 0])
 for r in csv.DictReader(open(cc)):
     if r["Counter_Name"] != "FETCH_SIZE":
         continue
-    k = r["Kernel_Name"].split("(")[0].split("<")[0][-40:]
+    k = "act_l2_norms_kernel" if "act_l2_norms_kernel" in r["Kernel_Name"] else r["Kernel_Name"].split("(")[0].split("<")[0][-40:]
     a = acc[k]; a[0] += float(r["Counter_Value"]); a[1] += 1; a[2] += dur.get(r["Dispatch_Id"], 0)
 out = {"lib_source_hash": _lib._source_hash(),
        "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --act-l2-only",
@@ -27,6 +27,10 @@ for k, (v, n, ns) in acc.items():
     if "act_l2" in k or "colsum" in k:
         b = v / n * 1024 * 2
         out[k] = {"launches": n, "hbm_bytes_per_launch": round(b), "avg_us": round(ns / n / 1e3, 2), "hbm_gbps": round(b / (ns / n), 1)}
+        if k == "act_l2_norms_kernel":
+            algo = 512 * 197 * 3072 * 2          # bench.py --act-l2-only: ViT-B/16, 512 images
+            out[k]["algorithmic_bytes"] = algo
+            out[k]["hbm_gbps_algorithmic"] = round(algo / (ns / n), 1)
 print(json.dumps(out, indent=1))
 P
 cat gpurun_out/pmc_act_l2.json
