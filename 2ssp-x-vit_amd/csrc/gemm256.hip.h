@@ -205,6 +205,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     TSTAMP(42);
     // K-tile 0 needs B(0), A(0).  Younger than those: A(1) (4 DMAs) on the first tile; on later tiles the whole
     // epilogue — whose last 4 VMEM operations are stores when it ran the full-tile path.
+    // (Round 2 experiment, null result: leaving the epilogue's 16 tail stores in flight here — vmcnt(20) instead of vmcnt(4) —
+    // changes nothing within the +-3 % run-to-run spread on any shape: wave 0's 5 k cycles at this barrier are the other
+    // waves' epilogues, which run at the HBM write rate when all 256 CUs store together, not its own store drain.)
     if (counted || (tiles_done == 1 && nk > 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else                                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     TSTAMP(41);

@@ -1,6 +1,7 @@
 // Standalone micro-benchmark of gemm_bf16_kernel<EPI> on random bf16 data (HIP events, median of rounds).
 //   gemm_bench.bin M N K epi [iters] [tokens]       epi: 0 bf16, 1 resid, 2 fc1(+score), 3 patch, 4 f32 (128x128 kernel);
-//   10/11/12 bf16/resid/fc1 on the persistent 256x256 kernel, 20/21/22 the same on its round-1 version (A/B)
+//   10/11/12 bf16/resid/fc1 on the persistent 256x256 kernel, 20/21/22 the same on its round-1 version (A/B),
+//   40/41/42 the same on the four-wave kernel (gemm256w4.hip.h), 30..33 e4m3 operands (gemm256 F8)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -9,6 +10,7 @@
 #include <cstring>
 #include <vector>
 #include "../gemm256.hip.h"
+#include "gemm256w4.hip.h"
 #include "gemm256_v1.hip.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -44,6 +46,12 @@ template <int EPI, int SCORE = 0> static void launch256(GemmArgs g, hipStream_t 
   if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS)); done = true; }
   g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
   hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(512), G256::LDS, s, g);
+}
+template <int EPI> static void launch256w4(GemmArgs g, hipStream_t s) {   // four-wave kernel (one wave per SIMD, 128 x 128 per wave)
+  static bool done = false;
+  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256W4::LDS)); done = true; }
+  g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
+  hipLaunchKernelGGL((gemm256w4_kernel<EPI>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(256), G256W4::LDS, s, g);
 }
 template <int EPI, int SCORE = 0> static void launch256f8(GemmArgs g, hipStream_t s) {   // e4m3 operands (gemm256 with F8 = true)
   static bool done = false;
@@ -99,7 +107,7 @@ static int run_fp8(int M, int N, int K, int epi, int iters, int tokens) {
       double acc = 0, mag = 0;
       for (int k = 0; k < K; ++k) { const double t = (double)fA[(size_t)m * K8 + k] * fW[(size_t)n * K8 + k]; acc += t; mag += fabs(t); }
       const float pre = bf2f(f2bf((float)(acc * hs[n]) + hb[n]));
-      const float sumtol = (float)(2e-6 * mag * hs[n]);          // fp32 summation-order error where the terms cancel
+      const float sumtol = (float)(4e-6 * mag * hs[n]);          // accumulation error where the terms cancel (the scaled MFMA aligns the products of a 64-deep step before adding: ~2e-6 of sum|terms| measured)
       ++checked;
       if (epi == 30) { const float got = bf2f(ho[(size_t)m * Npad + n]); const float d = fabsf(got - pre); const float tol = fabsf(pre) * 0.0079f + sumtol + 1e-6f; if (d > tol) { if (bad < 8) printf("  out[%d][%d] = %g, ref %g\n", m, n, got, pre); ++bad; } maxrel = std::max(maxrel, (double)d / (fabsf(pre) + 1e-3)); }
       else if (epi == 31) { const float got = hx[(size_t)m * Npad + n]; const float d = fabsf(got - pre); const float tol = fabsf(pre) * 0.0079f + sumtol + 1e-6f; if (d > tol) { if (bad < 8) printf("  x[%d][%d] = %g, ref %g\n", m, n, got, pre); ++bad; } maxrel = std::max(maxrel, (double)d / (fabsf(pre) + 1e-3)); }
@@ -151,6 +159,7 @@ int main(int argc, char** argv) {
                    case 3: launch<EPI_PATCH>(g, s); break; case 4: launch<EPI_F32>(g, s); break;
                    case 10: launch256<EPI_BF16>(g, s); break; case 11: launch256<EPI_RESID>(g, s); break;
                    case 12: launch256<EPI_FC1>(g, s); break; case 13: launch256<EPI_FC1, 1>(g, s); break; case 14: launch256<EPI_FC1, 2>(g, s); break;
+                   case 40: launch256w4<EPI_BF16>(g, s); break; case 41: launch256w4<EPI_RESID>(g, s); break; case 42: launch256w4<EPI_FC1>(g, s); break;
                    case 20: launch256v1<EPI_BF16, 8>(g, s); break; case 21: launch256v1<EPI_RESID, 8>(g, s); break;
                    case 22: launch256v1<EPI_FC1, 8>(g, s); break;
                    default: break; }
@@ -242,6 +251,21 @@ int main(int argc, char** argv) {
     }
     printf("stamps (cycles, wave 0 of every block): per-iteration issue+mfma %.0f  vmcnt-wait %.0f  barrier %.0f ; main loop per block %.0f ; kernel span %.0f\n",
            mfma / cnt, wait / cnt, bar / cnt, tot / nb, (double)(tmax - tmin));
+    if (epi >= 40 && epi < 50) {   // four-wave kernel: third tile of every workgroup (wave 0)
+      int G = std::min(((M + 255) / 256) * ((N + 255) / 256), nCU);
+      double pro = 0, ml = 0, ep = 0, w_l = 0, w_v = 0, w_b = 0, per = 0; long n = 0, nw = 0, np = 0;
+      for (int b = 0; b < G; ++b) {
+        const unsigned long long* t = &h[(size_t)b * 64];
+        if (!t[0] || !t[59] || !t[58]) continue;
+        pro += (double)(t[1] - t[0]); ml += (double)(t[58] - t[1]); ep += (double)(t[59] - t[58]); ++n;
+        for (int k = 0; k < nk - 1 && k < 14; ++k) {
+          w_l += (double)(t[3 + 4 * k] - t[2 + 4 * k]); w_v += (double)(t[4 + 4 * k] - t[3 + 4 * k]); w_b += (double)(t[5 + 4 * k] - t[4 + 4 * k]); ++nw;
+          if (k > 0) { per += (double)(t[2 + 4 * k] - t[2 + 4 * (k - 1)]); ++np; }
+        }
+      }
+      if (n) printf("w4 third tile (wave 0, avg of %ld workgroups, cycles): prologue (issue + wait + barrier) %.0f | main loop %.0f (K-tile period %.0f; at the barrier: lgkmcnt wait %.0f, vmcnt wait %.0f, barrier %.0f) | epilogue %.0f\n",
+                    n, pro / n, ml / n, np ? per / np : 0, w_l / nw, w_v / nw, w_b / nw, ep / n);
+    } else
     if (epi >= 10) {   // persistent kernel: per-workgroup totals
       int G = std::min(((M + 255) / 256) * ((N + 255) / 256), nCU);
       double cyc = 0, rt = 0, tl = 0;

@@ -107,7 +107,8 @@ def _pixels_to_device(batch, device) -> torch.Tensor:
     if cs is None:
         cs = _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
     cur = torch.cuda.current_stream(device)
-    cs.wait_stream(cur)                      # (the preprocessor's tables were uploaded on the creating stream)
+    # (no cs.wait_stream(cur): the preprocessor's tables were uploaded synchronously when it was created, and waiting for
+    # the compute stream here would park every later batch's copy behind the forwards already enqueued)
     with torch.cuda.stream(cs):
         out = pp(px, batch.get("hflip"))
     cur.wait_stream(cs)
@@ -193,9 +194,10 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
                 flush()
             eng = _resolve(engine, max(chunk_images, n))
             cap = min(eng.max_images, max(chunk_images, n))
-            if px.device.type == "cpu" and torch.device(eng.device).type == "cuda" and cap >= 4 * n:
-                # host batches: two launches instead of one, so that the copies of the second half overlap the forward
-                # of the first (scores do not depend on the packing: every batch is its own slab)
+            if px.device.type == "cpu" and px.dtype != torch.uint8 and torch.device(eng.device).type == "cuda" and cap >= 4 * n:
+                # fp32 host batches: two launches instead of one, so that the copies of the second half overlap the forward
+                # of the first (scores do not depend on the packing: every batch is its own slab); uint8 batches are a
+                # quarter of the bytes or less and keep the single large launch
                 cap = (cap // 2) // n * n
             ch = _Chunker(cap, eng.device, max_batches=MAX_SLABS)
         if ch.full_for(n):
