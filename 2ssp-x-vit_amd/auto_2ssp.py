@@ -143,10 +143,11 @@ def run_one(args, target, run_id):
                                           mlp_imp, att_imp, ffn_masks, pruned_indices)
         print(f"[FRAMEWORK] Exported to: {args.fw_export_prefix}_scores.json and {args.fw_export_prefix}_masks.json")
     if args.save_pruned_model:
-        pdir = Path(args.pruned_output_dir) / run_id
-        pdir.mkdir(parents=True, exist_ok=True)
-        torch.save(model.state_dict(), str(pdir / "timm_model.pth"))                 # reference :881-894 (timm branch)
-        arte["pruned_model_dir"] = str(pdir)
+        from ssp2vit import export
+        if args.save_format == "timm":                                               # reference :881-894 (timm / SRP branch)
+            arte["pruned_model_dir"] = export.save_timm_state_dict(model, args.pruned_output_dir, run_id)
+        else:                                                                        # reference :415-424, :896-901 (HF directory)
+            arte["pruned_model_dir"] = export.save_pruned_model_and_processor(model, None, Path(args.pruned_output_dir), run_id)
     pct = lambda a, b: round((a / max(1e-12, b) - 1) * 100, 1)
     drop = lambda a, b: round(((a - b) / max(1e-12, a)) * 100, 2) if (a is not None and b is not None) else None
     report = {
@@ -199,6 +200,8 @@ def build_argparser():
     p.add_argument("--force-copy-eval", action="store_true", help="accepted for compatibility (no MPS here)")
     p.add_argument("--save-pruned-model", action="store_true")
     p.add_argument("--pruned-output-dir", type=str, default=str(HERE / "pruned_models"))
+    p.add_argument("--save-format", type=str, default="timm", choices=["timm", "hf"],
+                   help="timm: state_dict file (the reference's --use-srp-checkpoint branch); hf: save_pretrained-style directory")
     p.add_argument("--fw-export-prefix", type=str, default=None)
     p.add_argument("--output-dir", type=str, default=str(HERE / "runs"), help="reports/ and artifacts/ are created below it")
     # synthetic stand-ins for the network-loaded model/data of the reference

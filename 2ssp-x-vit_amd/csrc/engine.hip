@@ -377,6 +377,14 @@ int ssp2_set_stream(ssp2_handle e, void* s) {
   return 0;
 }
 
+int ssp2_set_cu_limit(ssp2_handle e, int n_cu) {
+  if (!e) return fail(SSP2_EINVAL, "null handle");
+  int dev = 0; hipDeviceProp_t pr;
+  int phys = 256;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) phys = pr.multiProcessorCount;
+  e->n_cu = (n_cu <= 0 || n_cu > phys) ? phys : n_cu;
+  return 0;
+}
 int ssp2_tokens(ssp2_handle e) { return e ? e->tokens : SSP2_EINVAL; }
 int ssp2_query(ssp2_handle e, int what) {
   if (!e) return SSP2_EINVAL;

@@ -19,7 +19,7 @@ ABI_VERSION = 2                                         # SSP2_ABI_VERSION of in
 SYMBOLS = [
     "ssp2_abi_version", "ssp2_last_error", "ssp2_create", "ssp2_destroy", "ssp2_set_stream", "ssp2_load_tensor",
     "ssp2_load_tensor_dev", "ssp2_linear_bf16", "ssp2_query", "ssp2_restore_attention", "ssp2_clone_weights",
-    "ssp2_prune_ffn_into", "ssp2_set_precision",
+    "ssp2_prune_ffn_into", "ssp2_set_precision", "ssp2_set_cu_limit",
     "ssp2_embed", "ssp2_layers", "ssp2_head", "ssp2_tail", "ssp2_prune_ffn", "ssp2_drop_attention", "ssp2_d_int", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
     "ssp2_tokens", "ssp2_rows", "ssp2_workspace_bytes", "ssp2_preproc_create", "ssp2_preproc_run", "ssp2_preproc_destroy",
 ]
@@ -204,6 +204,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_tokens.argtypes = [vp]
     lib.ssp2_query.argtypes = [vp, i32]
     lib.ssp2_set_precision.argtypes = [vp, i32]
+    lib.ssp2_set_cu_limit.argtypes = [vp, i32]
     lib.ssp2_workspace_bytes.argtypes = [vp]
     lib.ssp2_workspace_bytes.restype = C.c_size_t
     lib.ssp2_preproc_create.argtypes = [i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(vp)]

@@ -121,6 +121,10 @@ class VitEngine:
             check(self.lib.ssp2_drop_attention(self.h, int(l)))
             self.absent[int(l)] = True
 
+    def set_cu_limit(self, n_cu: int) -> None:
+        """Cap the grids of this engine's persistent kernels at n_cu workgroups (0 = all CUs)."""
+        check(self.lib.ssp2_set_cu_limit(self.h, int(n_cu)))
+
     def pruned_twin(self, d_int: Sequence[int], max_images: int = 64) -> "VitEngine":
         """A second engine of the same architecture with FFN widths `d_int`, every other weight cloned device to
         device: the container `apply_into` fills.  Built once (outside a timed region); a prune then costs gathers only."""

@@ -71,6 +71,10 @@ const char* ssp2_last_error(void);
 int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out);
 int ssp2_destroy(ssp2_handle h);
 int ssp2_set_stream(ssp2_handle h, void* hip_stream);
+/* Cap the grids of the handle's persistent kernels (large-tile GEMMs, d_h = 64 attention) at n_cu workgroups (<= 0 or
+ * more than the device has: all CUs).  Two handles on two streams with half the CUs each run side by side instead of
+ * taking turns — the point of bench.py --two-streams. */
+int ssp2_set_cu_limit(ssp2_handle h, int n_cu);
 
 /* fp32 HOST data in nn.Linear/Conv2d layout ([out,in], conv [dim,3,p,p]); matrices are rounded to bf16
  * (RNE) exactly as torch.autocast casts them, biases are rounded to bf16 and kept as fp32 values, LayerNorm

@@ -328,3 +328,42 @@ def test_torch_ops_are_registered_with_the_declared_schemas():
     with pytest.raises(RuntimeError):
         ops.act_l2_accum(torch.zeros(2, 3, 8), 0)                    # CPU tensor: refused, there is no CPU path
     assert os.path.realpath(_lib.TORCH_OPS_PATH).startswith(os.path.realpath(PKG))
+
+
+def test_pruned_model_export_hf_directory_and_timm_state_dict(tmp_path):
+    """f2 export (reference auto_2ssp.py:415-424, :878-901): after a width prune + attention bypass the HF directory holds
+    config.json + model.safetensors with the PRUNED shapes and no attention weights for bypassed blocks, plus
+    pruning_meta.json; a real transformers model goes through its own save_pretrained, a build-owned container through
+    the safetensors writer; the timm branch writes timm_model.pth + srp_meta.json."""
+    from safetensors.torch import load_file
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import export, vit_pruning as vp
+    w, _, _ = load_tiny_golden("hf")
+    for layout in ("hf", "timm"):
+        m = build_from_flat(w, layout)
+        vp.prune_vit_mlp_width(m, n_to_prune_per_block=[40] * 4, min_remaining=16, strategy="l1")
+        vp.prune_vit_attention_blocks(m, sparsity=0.5, dataloader=None, importance_mode="heuristic", show_progress=False, num_to_prune=2)
+        d = export.save_pruned_model_and_processor(m, None, tmp_path, f"run_{layout}")
+        assert sorted(os.listdir(d)) == ["config.json", "model.safetensors", "pruning_meta.json"]
+        sd = load_file(os.path.join(d, "model.safetensors"))
+        assert set(sd) == set(m.state_dict()) and all(sd[k].shape == v.shape for k, v in m.state_dict().items())
+        meta = json.load(open(os.path.join(d, "pruning_meta.json")))
+        assert meta["ffn_width_per_block"] == [88] * 4 and meta["attention_removed_blocks"] == [0, 1] and meta["layout"] == layout
+        fc1 = "vit.encoder.layer.2.intermediate.dense.weight" if layout == "hf" else "blocks.2.mlp.fc1.weight"
+        assert sd[fc1].shape == (88, 64)
+        assert not any(("layer.0.attention" in k) or ("blocks.0.attn" in k) for k in sd)
+        assert json.load(open(os.path.join(d, "config.json")))["hidden_size"] == 64
+    t = export.save_timm_state_dict(m, tmp_path, "run_t")
+    assert sorted(os.listdir(t)) == ["srp_meta.json", "timm_model.pth"]
+    assert set(torch.load(os.path.join(t, "timm_model.pth"), weights_only=True)) == set(m.state_dict())
+    transformers = pytest.importorskip("transformers")
+    from transformers import ViTConfig, ViTForImageClassification
+    hf = ViTForImageClassification(ViTConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                                             image_size=32, patch_size=16, num_labels=10)).eval()
+    if vp._blocks(hf)[1] == "hf5":
+        vp.prune_vit_mlp_width(hf, n_to_prune_per_block=[40] * 2, min_remaining=16, strategy="l1")
+        d = export.save_pretrained_dir(hf, str(tmp_path / "hf5"))
+        assert {"config.json", "model.safetensors", "pruning_meta.json"} <= set(os.listdir(d))       # its own save_pretrained ran
+        sd = load_file(os.path.join(d, "model.safetensors"))           # (transformers 5 writes the checkpoint with the legacy key names)
+        key = "vit.layers.0.mlp.fc1.weight" if "vit.layers.0.mlp.fc1.weight" in sd else "vit.encoder.layer.0.intermediate.dense.weight"
+        assert sd[key].shape == (88, 64)
