@@ -28,6 +28,23 @@ __device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base)
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
 }
 
+// LDS stores that hipcc does not see as LDS stores.  While LDS-DMA operations are in flight the compiler puts an
+// `s_waitcnt vmcnt(0)` in front of the next ordinary store to LDS (it cannot tell that the two do not alias): in the GEMM
+// epilogues that drained the next tile's first K-tiles before the first staging write of EVERY wave.  The epilogues' staging
+// areas are never a DMA target while they are in use, so their stores go out as inline asm; the caller orders them against
+// the reads that follow with its own `s_waitcnt lgkmcnt(0)` (asm volatile with a memory clobber).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void lds_st_b8(void* p, uint32_t v) { asm volatile("ds_write_b8 %0, %1" :: "v"(lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st_b16(void* p, uint32_t v) { asm volatile("ds_write_b16 %0, %1" :: "v"(lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st_b32(void* p, uint32_t v) { asm volatile("ds_write_b32 %0, %1" :: "v"(lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st_b64(void* p, uint2 v) {
+  const unsigned long long d = ((unsigned long long)v.y << 32) | v.x;
+  asm volatile("ds_write_b64 %0, %1" :: "v"(lds_addr(p)), "v"(d) : "memory");
+}
+__device__ __forceinline__ void lds_st_b128(void* p, f32x4 v) { asm volatile("ds_write_b128 %0, %1" :: "v"(lds_addr(p)), "v"(v) : "memory"); }
+
 // exact (erf) GELU in fp32, the nn.GELU() default the reference models use
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -173,12 +173,18 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   };
 
   const int nk = g.K / KT;
+  // STREAM (nk >= 2): the K-tile stream does not stop at a tile boundary — the last two K-tiles of a tile carry the NEXT
+  // tile's A(0), B(0), A(1) in the very piece slots that would hold K-tiles nk, nk+1, and the ring (sa, sb) keeps turning
+  // across tiles.  Round 1 issued those 12 pieces per wave in one burst after the last K-tile (~3 k cycles per tile with
+  // nothing on the matrix pipe); riding behind MFMAs they cost ~50 cycles each of a COMPUTE phase.
+  const bool stream = nk >= 2;
+  int sa = C::A0, sb = C::B0;            // ring slots of the K-tile about to be read (persist across tiles)
   int tile = wg;
 #ifdef GEMM_STAGGER
-  // experiment: every second workgroup of an XCD starts g.group_m x 1024 cycles late, so that the residual epilogues'
-  // HBM bursts of the two halves interleave (timing builds of tools/gemm_bench only)
-  if (EPI == EPI_RESID && ((blockIdx.x >> 3) & 1))
-    for (int c = 0; c < g.group_m; ++c) __builtin_amdgcn_s_sleep(16);
+  // experiment (timing builds of tools/gemm_bench only): the workgroups of XCD group x = blockIdx.x & 7 start
+  // x * (group_m / 100) * 256 cycles late, so that the eight XCDs' epilogue bursts do not meet in HBM (workgroups of one XCD
+  // stay in step and keep sharing their operand panels through its L2)
+  for (int c = 0, n = (g.group_m / 100) * (blockIdx.x & 7); c < n; ++c) __builtin_amdgcn_s_sleep(4);
 #endif
   if (tile < ntiles) {
     set_tile(tile);
@@ -210,6 +216,14 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     // waves' epilogues, which run at the HBM write rate when all 256 CUs store together, not its own store drain.)
     if (counted || (tiles_done == 1 && nk > 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else                                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // This tile's bias (one column per lane; fp8: and its dequantisation scale) is taken over HERE: hipcc waits with
+    // vmcnt(0) for the (long finished) load in front of its first use, and this is the one point of the tile where nothing
+    // worth keeping in flight is in flight (at most the 4 A(1) pieces and the previous epilogue's last 4 stores) — at the
+    // start of the epilogue the same wait would drain the next tile's first K-tiles, which ride on the last two K-tiles.
+    float bias_lane = bias_next;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(bias_lane));
+    float wsc_lane = wsc_next;
+    if (F8) asm volatile("v_mov_b32 %0, %0" : "+v"(wsc_lane));
     TSTAMP(41);
     // ---- main loop: two wave groups in ping-pong.  A UNIT is half a K-tile: LOAD = 12 fragment reads
     // (ds_read_b128), COMPUTE = 16 MFMAs with 4 LDS-DMA pieces issued BETWEEN the MFMAs (behind pairs 0, 2, 4, 6; s_memtime stamps: a piece
@@ -225,20 +239,24 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     // counted wait retires its B(kt+1) and A(kt+1) pieces one barrier before their first read (phase 4kt+4).
     bf16x8 fa[2][C::TM], fb[2][C::TN];
     i32x8 ga[C::TM], gb[C::TN];                                // F8: one 64-deep step per unit, 32 bytes per lane and fragment
-    int sa = C::A0, sb = C::B0;
     uint32_t ride0[4], ride1[4];                               // the pieces carried in half 0 / half 1 (selected once per tile)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ride0[i] = wm ? a_src[i] : w_src[i]; ride1[i] = wm ? w_src[i] : a_src[i]; }
     ride_base0 = wm ? a_tile : w_tile;
     ride_base1 = wm ? w_tile : a_tile;
     if (wm) {                                                  // phase 0 of the tile: g1 has no unit to compute yet
-      if (nk > 1) stage_b(C::B1, 1);                           // its B(1) pieces (B1 is free: the tile-start barrier)
+      if (nk > 1) stage_b(sb ^ (C::B0 ^ C::B1), 1);            // its B(1) pieces (that slot is free: the tile-start barrier)
       asm volatile("s_barrier" ::: "memory");                  // the skew
     }
     // One K-tile.  B_ON / A_ON (is there a B(kt+1) / an A(kt+2) to fetch?) are compile-time: the steady state
     // (kt < nk - 2) carries no conditional around its DMA pieces, the last two K-tiles are separate instances.
-    auto ktile = [&](int kt, auto b_on_c, auto a_on_c) {
-      constexpr bool b_on = decltype(b_on_c)::value, a_on = decltype(a_on_c)::value;
+    //   kidx0 / kidx1: K-tile index (inside the panel ride_base0 / ride_base1 points at) of the pieces carried in half 0 / 1
+    //   STEADY (compile time): every unit carries its pieces, no conditional anywhere.  Otherwise `flags` decides at run
+    //   time (the last two K-tiles of a tile): bit 0 = g0's half-0 unit carries pieces, bit 2 = g1's half-1 unit does,
+    //   bit 1 = the other two units do.
+    auto ktile = [&](int kt, int kidx0, int kidx1, auto steady_c, int flags) {
+      constexpr bool STEADY = decltype(steady_c)::value;
+      const bool b_on = STEADY || (flags & 1), a_on = STEADY || (flags & 2), g1h1_on = STEADY || (flags & 4);
       const int sa1 = sa == C::A0 ? C::A1 : (sa == C::A1 ? C::A2 : C::A0);
       const int sa2 = sa1 == C::A0 ? C::A1 : (sa1 == C::A1 ? C::A2 : C::A0);
       const int sb1 = sb ^ (C::B0 ^ C::B1);
@@ -247,9 +265,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         //   half 0: g0 carries B(kt+1) -> sb1, g1 carries A(kt+2) -> sa2
         //   half 1: g0 carries A(kt+2) -> sa2, g1 carries B(kt+2) -> sb (K-tile kt's slot: its reads end with this LOAD)
         const bool take_a = (half == 0) == (wm != 0);
-        const bool dma_on = (half == 0 && !wm) ? b_on : a_on;
+        const bool dma_on = (half == 0 && !wm) ? b_on : ((half == 1 && wm) ? g1h1_on : a_on);
         const char* const dbase = (half == 0 ? ride_base0 : ride_base1)                      // wave-uniform: SGPRs
-                                  + (size_t)(((half == 0 && !wm) ? kt + 1 : kt + 2) * (GEMM_BK * 2));
+                                  + (size_t)((half == 0 ? kidx0 : kidx1) * (GEMM_BK * 2));
         const int dlds = take_a ? sa2 : (half == 0 ? sb1 : sb);
         const uint32_t (&dsrc)[4] = half == 0 ? ride0 : ride1;
         // PP_NL of the unit's 4 pieces go out in its LOAD phase (behind the fragment reads, in the time the wave would
@@ -352,33 +370,54 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       }
       sa = sa1; sb = sb1;
     };
+    const int cur_m0 = m0, cur_n0 = n0;                        // this tile's origin (m0 / n0 move on to the next tile below)
+    const int next = tile + G;
+    const bool has_next = stream && next < ntiles;
     {
+      using T_ = std::true_type; using F_ = std::false_type;
       int kt = 0;
-      for (; kt + 2 < nk; ++kt) ktile(kt, std::true_type{}, std::true_type{});
-      if (kt + 1 < nk) { ktile(kt, std::true_type{}, std::false_type{}); ++kt; }
-      if (kt < nk) ktile(kt, std::false_type{}, std::false_type{});
+      for (; kt + 2 < nk; ++kt) ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7);
+      if (kt + 1 < nk) {
+        // K-tile nk-2: g0's half 0 still carries this tile's B(nk-1); everything "two ahead" is the next tile's K-tile 0
+        int k0 = wm ? kt + 2 : kt + 1, k1 = kt + 2, fl = 1;
+        if (has_next) {
+          const char* const cur_w = w_tile;
+          set_tile(next);                                        // a_src, w_src, a_tile, w_tile, m0, n0 := the next tile's
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ride0[i] = wm ? a_src[i] : w_src[i]; ride1[i] = wm ? w_src[i] : a_src[i]; }
+          ride_base0 = wm ? a_tile : cur_w;
+          ride_base1 = wm ? w_tile : a_tile;
+          k0 = wm ? 0 : kt + 1; k1 = 0; fl = 7;
+        }
+        ktile(kt, k0, k1, F_{}, fl);
+        ++kt;
+      }
+      if (kt < nk) {
+        // K-tile nk-1: g0 carries B'(0) and A'(1), g1 A'(1); g1's half-1 unit (it would be B'(1), into THIS K-tile's B slot)
+        // stays empty — that slot and this K-tile's A slot are the epilogue's staging area; g1 fetches B'(1) at the tile start
+        if (has_next) ride_base0 = wm ? a_tile : w_tile;
+        ktile(kt, wm ? 1 : 0, 1, F_{}, has_next ? 3 : 0);
+      }
     }
     TSTAMP(60);
 
     // ---------------------------------------------------------------- epilogue
     // acc[a][b][4q + r]: row m = row0 + a*32 + l31 ; column n = col0 + b*32 + 8q + 4*lh + r
-    const int row0 = m0 + wm * 128, col0 = n0 + wn * 64;
-    const bool full = (m0 + C::BM <= g.M) && (n0 + C::BN <= g.N);    // workgroup-uniform
+    const int row0 = cur_m0 + wm * 128, col0 = cur_n0 + wn * 64;
+    const bool full = (cur_m0 + C::BM <= g.M) && (cur_n0 + C::BN <= g.N);    // workgroup-uniform
     const bool wave_cols_ok = col0 < g.N;
-    // this tile's bias, one column per lane; the VGPR is consumed here, BEFORE the next DMAs go out, so that the
-    // compiler's wait for the (long finished) bias load cannot land behind them and drain them
-    float bias_lane = bias_next;
-    asm volatile("v_mov_b32 %0, %0" : "+v"(bias_lane));
-    float wsc_lane = wsc_next;
-    if (F8) asm volatile("v_mov_b32 %0, %0" : "+v"(wsc_lane));
-    const int next = tile + G;
+    // staging area of the epilogue = the LAST K-tile's two slots (its reads are over; the next tile's first K-tiles go
+    // to the other three): waves 0-3 in its B slot, waves 4-7 in its A slot.  With nk a multiple of 6 that is B1 | A2.
+    const int stg_b = sb ^ (C::B0 ^ C::B1);
+    const int stg_a = sa == C::A0 ? C::A2 : (sa == C::A1 ? C::A0 : C::A1);
     if (next < ntiles) {
-      set_tile(next);
+      if (!has_next) {            // nk == 1: no K-tile to ride on — the next tile's first panels go out here, ring-relative
+        set_tile(next);
+        stage_b(sb, 0);
+        stage_a(sa, 0);
+      }
       bias_next = g.bias[n0 + wn * 64 + lane];
       if (F8) wsc_next = g.wscale[n0 + wn * 64 + lane];
-      stage_b(C::B0, 0);
-      stage_a(C::A0, 0);
-      if (nk > 1) stage_a(C::A1, 1);
     }
     TSTAMP(43);
     // Lane-derived epilogue constants are recomputed per tile behind an opaque copy of the lane id: hoisted out of the
@@ -387,32 +426,42 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     int le = lane;
     asm volatile("" : "+v"(le));
     const int l31e = le & 31, lhe = le >> 5;
+    // The 64 biases (and fp8 scales) of this wave's columns, four consecutive ones per (b, q): through the wave's own
+    // staging area — one ds_write_b32 per lane, eight ds_read_b128 — instead of 32 ds_bpermute shuffles (1.06 k cycles of
+    // every wave's epilogue under the stamps, a fifth of the bf16 epilogue).
+    char* const stg = smem + (wave < 4 ? stg_b : stg_a) + (wave & 3) * 8192;     // wave-private
     float bb[2][4][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bb[b][q][r] = __shfl(bias_lane, b * 32 + 8 * q + 4 * lhe + r);
     float sc[2][4][4];                                 // F8: the columns' dequantisation scales, same lane -> column map
-    if constexpr (F8 && SWAP) {
+    if constexpr (SWAP) {
+      lds_st_b32(stg + le * 4, __builtin_bit_cast(uint32_t, bias_lane));
+      if constexpr (F8) lds_st_b32(stg + 256 + le * 4, __builtin_bit_cast(uint32_t, wsc_lane));
+      WAITL0();
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *(const f32x4*)(stg + (b * 32 + 8 * q + 4 * lhe) * 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sc[b][q][r] = __shfl(wsc_lane, b * 32 + 8 * q + 4 * lhe + r);
+          for (int r = 0; r < 4; ++r) bb[b][q][r] = v[r];
+          if constexpr (F8) {
+            const f32x4 w = *(const f32x4*)(stg + 256 + (b * 32 + 8 * q + 4 * lhe) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[b][q][r] = w[r];
+          }
+        }
+      WAITL0();                                        // the values are in registers before the tile data overwrites the area
     }
     // pre-activation of element (a, b, 4q + r) before the bf16 rounding: acc + bias, or acc * wscale + bias on fp8 operands
     auto pre_f32 = [&](int a, int b, int q, int r) -> float {
       if constexpr (F8) return fmaf(acc[a][b][4 * q + r], sc[b][q][r], bb[b][q][r]);
       else return acc[a][b][4 * q + r] + bb[b][q][r];
     };
-    char* const stg = smem + C::STG + wave * 8192;     // wave-private
     counted = full && SWAP;
     // g0 is one barrier short of g1 (the skew): it pays it here, a few hundred cycles into its epilogue, while g1
     // issues its last 16 MFMAs.
+    TSTAMP(44);
     if (!wm) asm volatile("s_barrier" ::: "memory");
+    TSTAMP(45);
 
     if constexpr (!SWAP) {
       // ---- fc1 + GELU + stage-1 score, plain layout: acc[a][b][i]: row = row0 + a*32 + (i&3) + 8*(i>>2) + 4*lh,
@@ -465,12 +514,13 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
               }
               if constexpr (F8) {                         // e4m3 bytes of the bf16 activation, 64-byte staging rows
                 const uint32_t e = pack_e4m3x4(bf16lo_f32(o), bf16hi_f32(o), 0.f, 0.f);
-                *(uint8_t*)(stc + rw * 64) = (uint8_t)e;
-                *(uint8_t*)(stc + (rw + 1) * 64) = (uint8_t)(e >> 8);
+                lds_st_b8(stc + rw * 64, e);
+                lds_st_b8(stc + (rw + 1) * 64, e >> 8);
               } else {
                 const bf16x2 ov = __builtin_bit_cast(bf16x2, o);
-                *(bf16*)(stc + rw * 128) = ov[0];
-                *(bf16*)(stc + (rw + 1) * 128) = ov[1];
+                (void)ov;
+                lds_st_b16(stc + rw * 128, o);
+                lds_st_b16(stc + (rw + 1) * 128, o >> 16);
               }
             }
             if (plain && rb >= bnd) { ssq[h][1][b] += s0; } else { ssq[h][0][b] += s0; ssq[h][1][b] += s1; }
@@ -533,7 +583,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
                   gv[2 * p] = bf16lo_f32(o); gv[2 * p + 1] = bf16hi_f32(o);
                 }
                 const int r = a2 * 32 + l31e, chunk = 2 * b + (q >> 1);
-                *(uint32_t*)(stg + r * 64 + ((chunk ^ ((r >> 1) & 3)) << 4) + 8 * (q & 1) + 4 * lhe) = pack_e4m3x4(gv[0], gv[1], gv[2], gv[3]);
+                lds_st_b32(stg + r * 64 + ((chunk ^ ((r >> 1) & 3)) << 4) + 8 * (q & 1) + 4 * lhe, pack_e4m3x4(gv[0], gv[1], gv[2], gv[3]));
               }
           WAITL0();
           i32x4 v[4];
@@ -578,19 +628,22 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
                   }
                 }
                 uint2 v; v.x = pk[0]; v.y = pk[1];
-                *(uint2*)(wr_lane + a2 * 4096 + (((b * 4 + q) ^ (l31e & 7)) << 4)) = v;
+                lds_st_b64(wr_lane + a2 * 4096 + (((b * 4 + q) ^ (l31e & 7)) << 4), v);
               }
+          if (h == 0) TSTAMP(46);
           WAITL0();
           bf16x8 v[8];
 #pragma unroll
           for (int it = 0; it < 8; ++it) v[it] = *(const bf16x8*)(rd_lane + it * 1024);
           WAITL0();
+          if (h == 0) TSTAMP(47);
 #pragma unroll
           for (int it = 0; it < 8; ++it) {
             bf16* dst = out_lane + (size_t)(h * 64 + it * 8) * g.ldo;
             if (full) ST_OUT((bf16x8*)dst, v[it]);
             else if (row0 + h * 64 + it * 8 + (le >> 3) < g.M) ST_OUT((bf16x8*)dst, v[it]);
           }
+          if (h == 0) TSTAMP(48);
         }
       }
       // full path: the last 8 operations of this wave are the second pass's stores; the next main loop starts behind
@@ -650,7 +703,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             f32x4 v; v.x = acc[a][b][4 * q]; v.y = acc[a][b][4 * q + 1]; v.z = acc[a][b][4 * q + 2]; v.w = acc[a][b][4 * q + 3];
-            *(f32x4*)(cell_lane + buf + (((2 * q + lhe) ^ csw) << 4)) = v;
+            lds_st_b128(cell_lane + buf + (((2 * q + lhe) ^ csw) << 4), v);
           }
           WAITL0();
           f32x4 v[4];

@@ -283,6 +283,11 @@ int main(int argc, char** argv) {
             per += (double)(t[1 + 6 * k] - t[1 + 6 * (k - 1)]); ++nkt;
           }
         }
+        { double e[6] = {0,0,0,0,0,0}; long ne = 0;
+          for (int b = 0; b < G; ++b) { const unsigned long long* t = &h[(size_t)b * 64]; if (t[63] < 3 || !t[44] || !t[48]) continue;
+            e[0] += (double)(t[44] - t[43]); e[1] += (double)(t[45] - t[44]); e[2] += (double)(t[46] - t[45]); e[3] += (double)(t[47] - t[46]); e[4] += (double)(t[48] - t[47]); e[5] += (double)(t[40] - t[48]); ++ne; }
+          if (ne) printf("epilogue of the third tile (wave 0; bf16 / gelu paths): bias shuffles %.0f | skew barrier %.0f | pass 0: convert + LDS writes %.0f, LDS read-back %.0f, 8 stores %.0f | pass 1 %.0f\n",
+                         e[0] / ne, e[1] / ne, e[2] / ne, e[3] / ne, e[4] / ne, e[5] / ne); }
         if (n) printf("third tile (wave 0, avg of %ld workgroups, cycles): start-wait+barrier %.0f | main loop %.0f (K-tile period %.0f; first unit: 12 ds_read issue %.0f, lgkmcnt wait %.0f, barrier %.0f, 16 MFMA + 4 DMA issue %.0f) | next-tile set-up + DMA issue %.0f | epilogue %.0f\n",
                       n, w0 / n, ml / n, per / nkt, d[0] / nkt, d[1] / nkt, d[2] / nkt, d[3] / nkt, pf / n, ep / n);
       }
