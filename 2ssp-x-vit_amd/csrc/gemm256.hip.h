@@ -64,7 +64,11 @@
 #define ST_OUT(p, v) __builtin_nontemporal_store((v), (p))
 #else
 #define GLDS_A glds16
+#ifdef GEMM_ABL_NOSTORE   // ablation (timing builds of tools/gemm_bench only): the bf16 / GELU epilogue keeps its arithmetic and
+#define ST_OUT(p, v) asm volatile("" :: "v"(v))   // its LDS round trip but sends nothing to memory
+#else
 #define ST_OUT(p, v) (*(p) = (v))
+#endif
 #endif
 
 struct G256 {
