@@ -59,6 +59,75 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Sum over the 64 lanes, every lane gets the total, on the VALU only: four DPP adds (xor 1, xor 2, the other quad pair of
+// the 8-group, the other 8-group of the row) and the two gfx950 row / half swaps — ~50 cycles of dependent latency where
+// the ds_bpermute butterfly of wave_sum takes ~600.  Association (fixed): ((pairs) quads) 8-groups, rows 0+1 | 2+3,
+// halves.  (The permlane swaps are inline asm: with both operands equal, hipcc 7.2 folds the builtin's two results
+// into one and emits v_add v, v, v.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // a: rows 0 0 2 2, b: rows 1 1 3 3
+  v = a + b; a = v; b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // a: lower half twice, b: upper half twice
+  return a + b;
+}
+
+// four fp32 -> four e4m3 bytes (OCP fp8), saturating at +-448
+__device__ __forceinline__ uint32_t pack_e4m3x4_from(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+
+// One LayerNorm row, held by ONE wave: lane owns the float4 chunks lane, lane + 64, ... of the row (nv = D / 4 chunks,
+// chunks past nv are skipped).  Two-pass mean / variance in fp32, every multiply-add spelled out, so that the standalone
+// kernel (misc.hip.h) and the LayerNorm phase of the residual GEMM (gemm256.hip.h) produce the same bits from the
+// same row.  g4 / b4: the lane's chunks of gamma / beta; inv_d = 1 / D.  Output: bf16 rows (OUT8 = false, y = bf16*) or,
+// fp8 mode, the e4m3 bytes of the bf16-rounded values (OUT8 = true, y = uint8_t*).  FULL: D = 256 * MAXV exactly, no
+// chunk is predicated (straight-line code for the GEMM's phase).
+// The row statistics are wave-uniform values computed on the VALU of every lane, so their cost is per row, not per
+// element: sum * (1 / D) instead of a division, v_rsq_f32 + one Newton step instead of 1 / sqrt (both within 1 ulp of the
+// correctly rounded forms: 12 + 27 instructions of ~130 per row saved, which matters where the VALU is the bound — the GEMM's phase).
+template <int MAXV, bool FULL, bool OUT8>
+__device__ __forceinline__ void ln_row_finish(const f32x4 (&v)[MAXV], int lane, int nv, float inv_d, float eps, const f32x4 (&g4)[MAXV],
+                                              const f32x4 (&b4)[MAXV], void* y) {
+  // no contraction beyond the fmas written out below: left to hipcc, ONE of the four instances (the GEMM phase's e4m3 form)
+  // folded mean = sum * inv_d into the subtractions, v - sum * inv_d as one fma, and a few e4m3 bytes per launch differed
+#pragma clang fp contract(off)
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (FULL || i * 64 + lane < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum_dpp(s) * inv_d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (FULL || i * 64 + lane < nv) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q = __builtin_fmaf(d, d, q); }
+    }
+  const float var = __builtin_fmaf(wave_sum_dpp(q), inv_d, eps);
+  float rstd = __builtin_amdgcn_rsqf(var);
+  rstd = rstd * __builtin_fmaf(-0.5f * var * rstd, rstd, 1.5f);           // one Newton step on v_rsq_f32's 1-ulp estimate
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (FULL || c < nv) {
+      bf16x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (bf16)__builtin_fmaf((v[i][k] - mean) * rstd, g4[i][k], b4[i][k]);
+      if constexpr (OUT8) *(uint32_t*)((uint8_t*)y + c * 4) = pack_e4m3x4_from((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+      else *(bf16x4*)((bf16*)y + c * 4) = o;
+    }
+  }
+}
+
 // XCD-aware bijective remap of a 1-D grid (blocks b and b+8 share an XCD): each XCD walks a contiguous
 // range of logical tile ids, so neighbours that share an operand panel hit the same 4 MiB L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -169,9 +169,49 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
     attr_done = true;
   }
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
-  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE, F8>), dim3(std::min(g.tiles_m * g.tiles_n, e->n_cu)), dim3(512), G256::LDS, e->stream, g);
+  // EPI_RESID with SCORE > 0 = LayerNorm fused behind the epilogue: one workgroup per ROW PANEL (it owns all its column tiles)
+  const int wgs = (EPI == EPI_RESID && SCORE > 0) ? std::min(g.tiles_m, e->n_cu) : std::min(g.tiles_m * g.tiles_n, e->n_cu);
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE, F8>), dim3(wgs), dim3(512), G256::LDS, e->stream, g);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+// The residual projections (attention out-proj, fc2) can normalise the rows they finish — the LayerNorm that feeds the
+// NEXT projection — inside the GEMM kernel (gemm256.hip.h, LNV): the standalone kernel (4.5 KB per row through HBM, 9 % of
+// the step) then does not run.  OPT-IN (SSP2_LN_FUSION=1), because it does not pay as built (profiles/r02_d_gemm_ln_fusion.txt):
+// a workgroup must own whole 256-row panels, i.e. walk a panel's dim / 256 column tiles one after the other, and so reads
+// its A panel that many times from the Infinity Cache / HBM instead of sharing it through the XCD's L2 with the workgroups
+// that take the other column tiles at the same time (32 x 393 KB per XCD do not stay in 4 MiB): out-proj 117 -> 145 us,
+// fc2 334 -> 391 us for 63040 rows, and the phase itself is VALU-bound at ~25 us per panel (180 instructions per row, two
+// waves per SIMD) against 50-60 us for the standalone launch — out-proj + LN 177 -> 170 us, fc2 + LN 394 -> 416 us.
+// Results are bit-identical either way (one row routine, ln_row_finish; tests/test_gpu_parity.py).
+// Conditions when switched on: the launch goes to the 256 x 256 kernel, dim = 3, 4 or 5 column tiles, and a cost model in
+// cycles says the fused form is the cheaper one.  Returns dim / 256 or 0.
+static int ln_fusable(const ssp2_engine* e, int M, int K, bool f8) {
+  const int D = e->d.dim;
+  const char* on = getenv("SSP2_LN_FUSION");
+  if (!on || on[0] == '0' || M < kBigTileMinRows || D % 256 || D / 256 < 3 || D / 256 > 5 || getenv("SSP2_NO_BIG_TILES")) return 0;
+  if (on[0] == '2') return D / 256;          // 2: always (tests: both residual projections of every layer)
+  const int tn = D / 256, tm = (M + 255) / 256, cu = e->n_cu;
+  const int rounds_fused = (tm + cu - 1) / cu * tn, rounds_plain = (tm * tn + cu - 1) / cu;
+  // cycles (≈1.86 GHz): a K-tile of the main loop 2.6 k (fp8: K-tiles of 128), tile change 9 k; the A panel's tn - 1 extra
+  // reads at ~8 TB/s from the Infinity Cache when A fits there, ~5 TB/s otherwise, half of it hidden; LayerNorm: standalone
+  // 4.5 KB per row at 5 TB/s, fused ≈ 46 k (25 us) per panel of 256 rows
+  const double tile_cyc = (double)(K / (f8 ? 128 : 64)) * 2600.0 + 9000.0;
+  const double a_bytes = (double)M * K * (f8 ? 1 : 2);
+  const double reread = 0.5 * (tn - 1) * a_bytes / (a_bytes < 200e6 ? 8e12 : 5e12) * 1.86e9;
+  const double ln_alone = (double)M * 4608.0 / 5.0e12 * 1.86e9 + 6000.0;
+  const double ln_fused = (double)((tm + cu - 1) / cu) * 46000.0 + reread;
+  return (rounds_fused - rounds_plain) * tile_cyc + ln_fused < ln_alone ? tn : 0;
+}
+template <bool F8>
+static int launch_resid_ln(ssp2_engine* e, const GemmArgs& g, int lnv, int klass) {
+  switch (lnv) {
+    case 3: return launch_gemm256<EPI_RESID, 3, F8>(e, g, klass);
+    case 4: return launch_gemm256<EPI_RESID, 4, F8>(e, g, klass);
+    case 5: return launch_gemm256<EPI_RESID, 5, F8>(e, g, klass);
+    default: return fail(SSP2_EINVAL, "fused LayerNorm: dim / 256 = %d unsupported", lnv);
+  }
 }
 
 template <int EPI, int SCORE = 0>
@@ -567,46 +607,58 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
   const int n_groups = (n + grp - 1) / grp;
   const size_t group_stride = (size_t)e->d.depth * score_ld;
   const bool fused = score_site && e->tokens >= GEMM_BM;   // a 128-row tile then spans at most two samples
+  // fp8 mode: the three large projections of a launch with >= 4096 rows run on e4m3 operands (LayerNorm and the fc1
+  // epilogue write the activation as e4m3 bytes); attention, the out-projection and small launches stay bf16
+  const bool f8 = e->fp8 && M >= kBigTileMinRows;
+  const bool f8_fc1 = f8 && fused_ok_for_fp8(score_site, e->tokens);
+  bool h_ready = false;          // hbuf / hbuf8 already holds the LayerNorm the next projection reads (written by a residual GEMM)
+  auto set_ln = [&](GemmArgs& a, const float* gm, const float* bt, bool to_fp8) {
+    a.ln_g = gm; a.ln_b = bt; a.ln_eps = e->d.ln_eps;
+    if (to_fp8) { a.ln_out8 = e->hbuf8; a.ln_ld = e->ld8_dim; } else { a.ln_out = e->hbuf; a.ln_ld = D; }
+  };
   for (int l = l_begin; l < l_end; ++l) {
     Layer& L = e->layers[l];
     const bool skip = L.attn_dropped || (attn_skip && attn_skip[l]);
     if (!(L.ln_set[2] && L.ln_set[3] && L.fc1.w_set && L.fc1.b_set && L.fc2.w_set && L.fc2.b_set))
       return fail(SSP2_ESTATE, "layer %d MLP weights not loaded", l);
-    // fp8 mode: the three large projections of a launch with >= 4096 rows run on e4m3 operands (LayerNorm and the fc1
-    // epilogue write the activation as e4m3 bytes); attention, the out-projection and small launches stay bf16
-    const bool f8 = e->fp8 && M >= kBigTileMinRows;
     if (!skip) {
       if (!(L.ln_set[0] && L.ln_set[1] && L.qkv.w_set && L.qkv.b_set && L.proj.w_set && L.proj.b_set))
         return fail(SSP2_ESTATE, "layer %d attention weights not loaded", l);
       GemmArgs q{};
       q.bias = L.qkv.b; q.M = M; q.N = 3 * D; q.tiles_n = L.qkv.rows_pad / GEMM_BN; q.out = e->qkvbuf; q.ldo = 3 * D;
       if (f8) {
-        if ((rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
+        if (!h_ready && (rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
         q.A = (const bf16*)e->hbuf8; q.lda = e->ld8_dim; q.W = (const bf16*)L.qkv.w8; q.ldw = L.qkv.ld8; q.K = e->ld8_dim; q.wscale = L.qkv.wscale;
         if ((rc = launch_gemm256<EPI_BF16, 0, true>(e, q, SSP2_K_GEMM_QKV))) return rc;
       } else {
-        if ((rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, e->hbuf, D, M, D))) return rc;
+        if (!h_ready && (rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, e->hbuf, D, M, D))) return rc;
         q.A = e->hbuf; q.lda = D; q.W = L.qkv.w; q.ldw = L.qkv.ld; q.K = D;
         if ((rc = launch_gemm<EPI_BF16>(e, q, SSP2_K_GEMM_QKV))) return rc;
       }
+      h_ready = false;
       if ((rc = launch_attn(e, n, rm))) return rc;
       GemmArgs p{};
       p.A = e->obuf; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.bias = L.proj.b;
       p.M = M; p.N = D; p.K = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = x; p.ldx = D;
-      if ((rc = launch_gemm<EPI_RESID>(e, p, SSP2_K_GEMM_PROJ))) return rc;
+      if (const int lnv = ln_fusable(e, M, D, false)) {          // + LN2 of this layer: fc1's operand
+        set_ln(p, L.ln2_g, L.ln2_b, f8_fc1);
+        if ((rc = launch_resid_ln<false>(e, p, lnv, SSP2_K_GEMM_PROJ))) return rc;
+        h_ready = true;
+      } else if ((rc = launch_gemm<EPI_RESID>(e, p, SSP2_K_GEMM_PROJ))) return rc;
     }
     const int ld8_int = ceil_to(L.ld_int, 128);
     GemmArgs f{};
     f.bias = L.fc1.b; f.M = M; f.tiles_n = L.fc1.rows_pad / GEMM_BN;
-    if (f8 && fused_ok_for_fp8(score_site, e->tokens)) {
-      if ((rc = launch_ln(e, x, D, L.ln2_g, L.ln2_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
+    if (f8_fc1) {
+      if (!h_ready && (rc = launch_ln(e, x, D, L.ln2_g, L.ln2_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
       f.A = (const bf16*)e->hbuf8; f.lda = e->ld8_dim; f.W = (const bf16*)L.fc1.w8; f.ldw = L.fc1.ld8; f.K = e->ld8_dim; f.wscale = L.fc1.wscale;
       f.N = ld8_int; f.out = (bf16*)e->act8; f.ldo = ld8_int;      // e4m3 bytes out; the pad columns up to 128 are written (zeros)
     } else {
-      if ((rc = launch_ln(e, x, D, L.ln2_g, L.ln2_b, e->hbuf, D, M, D))) return rc;
+      if (!h_ready && (rc = launch_ln(e, x, D, L.ln2_g, L.ln2_b, e->hbuf, D, M, D))) return rc;
       f.A = e->hbuf; f.lda = D; f.W = L.fc1.w; f.ldw = L.fc1.ld; f.K = D;
       f.N = L.ld_int; f.out = e->actbuf; f.ldo = L.ld_int;
     }
+    h_ready = false;
     const bool f8_mlp = f.wscale != nullptr;
     f.score_site = fused ? score_site : 0; f.tokens = e->tokens; f.slab = e->slab; f.slab_ld = L.ld_int;
     f.group = rm.group; f.mpad = rm.mpad; f.n_img = n;
@@ -641,13 +693,24 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
     }
     GemmArgs o{};
     o.bias = L.fc2.b; o.M = M; o.N = D; o.tiles_n = L.fc2.rows_pad / GEMM_BN; o.x = x; o.ldx = D;
+    // + the LayerNorm the NEXT layer of this call starts with: LN1 of layer l + 1, or its LN2 when its attention is skipped
+    int lnv = 0;
+    if (l + 1 < l_end) {
+      Layer& Ln = e->layers[l + 1];
+      const bool skip_n = Ln.attn_dropped || (attn_skip && attn_skip[l + 1]);
+      if (skip_n ? (Ln.ln_set[2] && Ln.ln_set[3]) : (Ln.ln_set[0] && Ln.ln_set[1])) {
+        lnv = ln_fusable(e, M, f8_mlp ? ld8_int : L.ld_int, f8_mlp);
+        if (lnv) set_ln(o, skip_n ? Ln.ln2_g : Ln.ln1_g, skip_n ? Ln.ln2_b : Ln.ln1_b, skip_n ? f8_fc1 : f8);
+      }
+    }
     if (f8_mlp) {
       o.A = (const bf16*)e->act8; o.lda = ld8_int; o.W = (const bf16*)L.fc2.w8; o.ldw = L.fc2.ld8; o.K = ld8_int; o.wscale = L.fc2.wscale;
-      if ((rc = launch_gemm256<EPI_RESID, 0, true>(e, o, SSP2_K_GEMM_FC2))) return rc;
+      if ((rc = lnv ? launch_resid_ln<true>(e, o, lnv, SSP2_K_GEMM_FC2) : launch_gemm256<EPI_RESID, 0, true>(e, o, SSP2_K_GEMM_FC2))) return rc;
     } else {
       o.A = e->actbuf; o.lda = L.ld_int; o.W = L.fc2.w; o.ldw = L.fc2.ld; o.K = L.ld_int;
-      if ((rc = launch_gemm<EPI_RESID>(e, o, SSP2_K_GEMM_FC2))) return rc;
+      if ((rc = lnv ? launch_resid_ln<false>(e, o, lnv, SSP2_K_GEMM_FC2) : launch_gemm<EPI_RESID>(e, o, SSP2_K_GEMM_FC2))) return rc;
     }
+    h_ready = lnv != 0;
   }
   return 0;
 }
@@ -988,10 +1051,11 @@ static int act_l2_impl(void* stream, const void* act, int dtype, int n, RowMap r
   if (n <= 0 || tokens <= 0 || d <= 0 || ld < d || (ld % 8)) return fail(SSP2_EINVAL, "bad shape n=%d tokens=%d d=%d ld=%d (ld multiple of 8, >= d)", n, tokens, d, ld);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((ld + 511) / 512, n, 2), blk(256);       // z = token half (see act_l2_norms_kernel)
+  // non-temporal loads: the activation is read once (5.28 -> 5.78 TB/s on the 512-image tensor, profiles/r02_d_act_l2_nt_ab.txt)
   if (dtype == 0)
-    hipLaunchKernelGGL(act_l2_norms_kernel<bf16>, grid, blk, 0, s, (const bf16*)act, norms_ws, rm, ld, n);
+    hipLaunchKernelGGL((act_l2_norms_kernel<bf16, 1>), grid, blk, 0, s, (const bf16*)act, norms_ws, rm, ld, n);
   else if (dtype == 1)
-    hipLaunchKernelGGL(act_l2_norms_kernel<float>, grid, blk, 0, s, (const float*)act, norms_ws, rm, ld, n);
+    hipLaunchKernelGGL((act_l2_norms_kernel<float, 1>), grid, blk, 0, s, (const float*)act, norms_ws, rm, ld, n);
   else
     return fail(SSP2_EINVAL, "dtype %d (0 = bf16, 1 = f32)", dtype);
   const int grp = (group <= 0 || group > n) ? n : group;

@@ -98,6 +98,7 @@ template <int EPI, int SCORE = 0, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   using C = G256;
   constexpr bool SWAP = !(EPI == EPI_FC1 && SCORE != 0);
+  constexpr int LNV = EPI == EPI_RESID ? SCORE : 0;     // > 0: LayerNorm of the finished row panels, N = LNV * 256 (see below)
   constexpr int ESZ = F8 ? 1 : 2;                       // bytes per operand element
   constexpr int KT = F8 ? 128 : GEMM_BK;                // K elements per K-tile (128 bytes per LDS row either way)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -154,10 +155,14 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       tm = tile / g.tiles_n; tn = tile - tm * g.tiles_n;            // N fastest: neighbours share the A panel
     }
     m0 = tm * C::BM; n0 = tn * C::BN;
+    // the lane-derived parts are recomputed per tile from an opaque lane id (a handful of VALU operations): hoisted out of
+    // the tile loop they are 12 more VGPRs across a main loop that lives at the 256-register limit
+    int ls = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ls));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = (wave + 8 * i) * 8 + (lane >> 3);
-      const int c_src = (lane & 7) ^ ((row >> 1) & 7);
+      const int row = (wave + 8 * i) * 8 + (ls >> 3);
+      const int c_src = (ls & 7) ^ ((row >> 1) & 7);
       int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
       a_src[i] = (uint32_t)(gr - m0) * (uint32_t)g.lda * ESZ + c_src * 16;
       w_src[i] = (uint32_t)row * (uint32_t)g.ldw * ESZ + c_src * 16;
@@ -183,7 +188,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   // nothing on the matrix pipe); riding behind MFMAs they cost ~50 cycles each of a COMPUTE phase.
   const bool stream = nk >= 2;
   int sa = C::A0, sb = C::B0;            // ring slots of the K-tile about to be read (persist across tiles)
-  int tile = wg;
+  // Tile walk.  Plain: tiles wg, wg + G, ... of the N-fastest numbering.  LNV: a workgroup owns whole ROW PANELS
+  // (wg, wg + G, ...) and takes a panel's tiles_n column tiles back to back — the same numbering, another successor.
+  int tile = LNV ? wg * g.tiles_n : wg;
+  auto next_of = [&](int t) { return LNV ? ((t + 1) % g.tiles_n ? t + 1 : t + 1 + (G - 1) * g.tiles_n) : t + G; };
 #ifdef GEMM_STAGGER
   // experiment (timing builds of tools/gemm_bench only): the workgroups of XCD group x = blockIdx.x & 7 start
   // x * (group_m / 100) * 256 cycles late, so that the eight XCDs' epilogue bursts do not meet in HBM (workgroups of one XCD
@@ -202,7 +210,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   RSTAMP(61);
   int tiles_done = 0;
   bool counted = false;                // previous epilogue took the full-tile path: its last stores may stay in flight
-  for (; tile < ntiles; tile += G) {
+  bool ln_flushed = false;             // previous tile ended with a LayerNorm phase: every DMA and store before it has landed
+  for (; tile < ntiles; tile = next_of(tile)) {
     ++tiles_done;
     f32x16 acc[C::TM][C::TN];
 #pragma unroll
@@ -218,8 +227,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     // (Round 2 experiment, null result: leaving the epilogue's 16 tail stores in flight here — vmcnt(20) instead of vmcnt(4) —
     // changes nothing within the +-3 % run-to-run spread on any shape: wave 0's 5 k cycles at this barrier are the other
     // waves' epilogues, which run at the HBM write rate when all 256 CUs store together, not its own store drain.)
-    if (counted || (tiles_done == 1 && nk > 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else                                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (LNV && ln_flushed)                           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // only h stores in flight
+    else if (counted || (tiles_done == 1 && nk > 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else                                             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ln_flushed = false;
     // This tile's bias (one column per lane; fp8: and its dequantisation scale) is taken over HERE: hipcc waits with
     // vmcnt(0) for the (long finished) load in front of its first use, and this is the one point of the tile where nothing
     // worth keeping in flight is in flight (at most the 4 A(1) pieces and the previous epilogue's last 4 stores) — at the
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       sa = sa1; sb = sb1;
     };
     const int cur_m0 = m0, cur_n0 = n0;                        // this tile's origin (m0 / n0 move on to the next tile below)
-    const int next = tile + G;
+    const int next = next_of(tile);
     const bool has_next = stream && next < ntiles;
     {
       using T_ = std::true_type; using F_ = std::false_type;
@@ -736,6 +747,74 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+      }
+    }
+    if constexpr (LNV > 0) {
+      // ---------------------------------------------------------------- LayerNorm of the finished panel
+      // The panel's last column tile is done: its 256 rows of x are complete, and they are in this XCD's L2 (this very
+      // workgroup wrote them).  Wave w normalises rows w, w + 8, ... exactly as layernorm_bf16_kernel does (one wave per
+      // row, ln_row_finish), R rows per batch with the next batch's loads in flight.  The standalone kernel moves 4.5 KB per
+      // row through HBM (5.6 TB/s: 52 us per 63040 rows); here the reads are L2 hits and only the bf16 rows leave.
+      if (cur_n0 + C::BN >= g.N) {
+        // every wave's x stores must have reached L2 before another wave reads them: vmcnt(0) (a store counts until it is
+        // acknowledged) + workgroup barrier; waves of one workgroup share the CU's vector L1, which is write-through
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        int ll = lane;
+        asm volatile("" : "+v"(ll));                 // opaque: nothing below may be hoisted over the main loop (registers)
+        const int nv = g.N >> 2;
+        f32x4 g4[LNV], b4[LNV];
+#pragma unroll
+        for (int i = 0; i < LNV; ++i) {
+          g4[i] = ((const f32x4*)g.ln_g)[i * 64 + ll]; b4[i] = ((const f32x4*)g.ln_b)[i * 64 + ll];     // N = 256 * LNV: every chunk exists
+        }
+        const int rows_here = g.M - cur_m0 < C::BM ? g.M - cur_m0 : C::BM;
+        const float inv_d = 1.0f / (float)g.N;
+        // wave w: rows w, w + 8, ... (32 of them), two register sets in ping-pong: the loads of row i + 1 are in flight
+        // while row i is normalised.  The loads are inline asm with a counted wait of our own (as for the LDS-DMA): left to
+        // hipcc, every row waited with vmcnt(0) — for its own loads AND the previous row's stores, 1.9 us per row.
+        const uint32_t ll16 = (uint32_t)ll * 16;
+        auto load_row = [&](f32x4 (&dst)[LNV], int i) {
+          int r = wave + 8 * i;
+          r = r < rows_here ? r : rows_here - 1;
+          const char* xr = (const char*)(g.x + (size_t)(cur_m0 + r) * g.ldx);
+#pragma unroll
+          for (int c = 0; c < LNV; ++c)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst[c]) : "v"(ll16), "s"(xr + c * 1024) : "memory");
+        };
+        // a counted wait that the row registers pass through (no use moves above it): all but the N youngest vector-memory
+        // operations have landed
+        auto landed = [&](f32x4 (&d)[LNV], auto n_c) {
+          constexpr int N = decltype(n_c)::value;
+          if constexpr (LNV == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]) : "n"(N) : "memory");
+          if constexpr (LNV == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "n"(N) : "memory");
+          if constexpr (LNV == 5) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]) : "n"(N) : "memory");
+        };
+        auto rows = [&](auto out8_c) {
+          constexpr bool OUT8 = decltype(out8_c)::value;
+          // rows past the panel's end (last panel only) are clamped to its last row for the load AND the store: the same
+          // bits land on the same address again, and every row costs exactly LNV loads + LNV stores — the counts below
+          auto finish = [&](const f32x4 (&src)[LNV], int i) {
+            int r = wave + 8 * i;
+            r = r < rows_here ? r : rows_here - 1;
+            const size_t ro = (size_t)(cur_m0 + r) * g.ln_ld;
+            ln_row_finish<LNV, true, OUT8>(src, ll, nv, inv_d, g.ln_eps, g4, b4, OUT8 ? (void*)(g.ln_out8 + ro) : (void*)(g.ln_out + ro));
+          };
+          using N1 = std::integral_constant<int, LNV>;        // younger than the set: the other set's loads
+          using N2 = std::integral_constant<int, 2 * LNV>;    // ... and the previous row's stores (waiting for THOSE cost ~1 us per row)
+          f32x4 ra[LNV], rb[LNV];
+          load_row(ra, 0);
+          load_row(rb, 1);
+          landed(ra, N1{}); finish(ra, 0); load_row(ra, 2);
+#pragma unroll 1
+          for (int i = 1; i < 31; i += 2) {
+            landed(rb, N2{}); finish(rb, i); load_row(rb, i + 2);                           // i + 2 <= 31
+            landed(ra, N2{}); finish(ra, i + 1); load_row(ra, i + 3 < 32 ? i + 3 : 31);     // (the last one is a redundant re-load)
+          }
+          landed(rb, N2{}); finish(rb, 31);
+          landed(ra, std::integral_constant<int, 0>{});     // nothing may still be landing in registers the compiler re-uses
+        };
+        if (g.ln_out8) rows(std::true_type{}); else rows(std::false_type{});
+        ln_flushed = true;
       }
     }
     TSTAMP(40);

@@ -43,15 +43,6 @@ __global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ 
   }
 }
 
-// four fp32 -> four e4m3 bytes, saturating (same arithmetic as gemm.hip.h pack_e4m3x4; this header is included first)
-__device__ __forceinline__ uint32_t pack_e4m3x4_from(float a, float b, float c, float d) {
-  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
-  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  return (uint32_t)w;
-}
-
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: fp32 rows -> bf16 rows.  One wave per row, the row lives in registers
 // (two-pass mean / variance in fp32), 16-byte loads and 8-byte stores (lane owns float4 chunks lane, lane+64, ..).
@@ -69,38 +60,16 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   // gather.tokens > 0: output row r is the CLS row of image r (slab layout aware); else input row r*in_stride
   const f32x4* xr = (const f32x4*)(gather.tokens > 0 ? x + (size_t)row_of(gather, row) * D : x + (size_t)row * in_stride);
   const int nv = D >> 2;                      // float4 chunks in the row
-  f32x4 v[MAXV];
-  float s = 0.f;
+  f32x4 v[MAXV], g4[MAXV], b4[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = i * 64 + lane;
-    if (c < nv) { v[i] = xr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    if (c < nv) { v[i] = xr[c]; g4[i] = ((const f32x4*)gamma)[c]; b4[i] = ((const f32x4*)beta)[c]; }
   }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = i * 64 + lane;
-    if (c < nv) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q += d * d; }
-    }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-  bf16* yr = y + (size_t)row * out_ld;
-  uint8_t* yr8 = y8 ? y8 + (size_t)row * out_ld : nullptr;   // fp8 mode: e4m3 bytes (of the bf16-rounded value), out_ld in bytes
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = i * 64 + lane;
-    if (c < nv) {
-      const f32x4 g4 = ((const f32x4*)gamma)[c], b4 = ((const f32x4*)beta)[c];
-      bf16x4 o;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = (bf16)((v[i][k] - mean) * rstd * g4[k] + b4[k]);
-      if (yr8) *(uint32_t*)(yr8 + c * 4) = pack_e4m3x4_from((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
-      else *(bf16x4*)(yr + c * 4) = o;
-    }
-  }
+  // fp8 mode: e4m3 bytes (of the bf16-rounded value), out_ld in bytes
+  const float inv_d = 1.0f / (float)D;
+  if (y8) ln_row_finish<MAXV, false, true>(v, lane, nv, inv_d, eps, g4, b4, y8 + (size_t)row * out_ld);
+  else    ln_row_finish<MAXV, false, false>(v, lane, nv, inv_d, eps, g4, b4, y + (size_t)row * out_ld);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -154,22 +123,34 @@ __global__ void score_colsum_kernel(const float* __restrict__ norms, float* __re
 //   act [n, tokens, ld] (bf16 or f32) ; norms[s][j] = sqrt(sum_t act[s,t,j]^2)
 // grid (ld/512, n); 256 threads: wave w streams tokens w, w+4, ... ; lane owns 8 consecutive neurons
 // (one 16-B load per token row for bf16), 16 token rows in flight per wave; cross-wave fold through LDS.
-template <typename T>
+template <typename T, int NT = 0>
 __device__ __forceinline__ void load8(const T* p, float (&f)[8]);
 template <>
-__device__ __forceinline__ void load8<bf16>(const bf16* p, float (&f)[8]) {
+__device__ __forceinline__ void load8<bf16, 0>(const bf16* p, float (&f)[8]) {
   const bf16x8 v = *(const bf16x8*)p;
 #pragma unroll
   for (int k = 0; k < 8; ++k) f[k] = (float)v[k];
 }
 template <>
-__device__ __forceinline__ void load8<float>(const float* p, float (&f)[8]) {
+__device__ __forceinline__ void load8<bf16, 1>(const bf16* p, float (&f)[8]) {
+  const bf16x8 v = __builtin_nontemporal_load((const bf16x8*)p);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) f[k] = (float)v[k];
+}
+template <>
+__device__ __forceinline__ void load8<float, 0>(const float* p, float (&f)[8]) {
   const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
 #pragma unroll
   for (int k = 0; k < 4; ++k) { f[k] = a[k]; f[4 + k] = b[k]; }
 }
+template <>
+__device__ __forceinline__ void load8<float, 1>(const float* p, float (&f)[8]) {
+  const f32x4 a = __builtin_nontemporal_load((const f32x4*)p), b = __builtin_nontemporal_load((const f32x4*)(p + 4));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { f[k] = a[k]; f[4 + k] = b[k]; }
+}
 
-template <typename T>
+template <typename T, int NT = 0>
 __global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__ act, float* __restrict__ ssq_ws,
                                                           RowMap rm, int ld, int n) {
   // grid (ld/512, n, 2): blockIdx.z = token half.  One (sample, 512-column chunk) per block gave 6 x 64 = 384 blocks for
@@ -195,7 +176,7 @@ __global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__
     for (; t + 60 < t_end; t += 64) {
       float f[16][8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) load8<T>(base + (size_t)(t + 4 * r) * ld, f[r]);
+      for (int r = 0; r < 16; ++r) load8<T, NT>(base + (size_t)(t + 4 * r) * ld, f[r]);
 #pragma unroll
       for (int r = 0; r < 16; r += 4)
 #pragma unroll
@@ -204,7 +185,7 @@ __global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__
     for (; t + 28 < t_end; t += 32) {
       float f[8][8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) load8<T>(base + (size_t)(t + 4 * r) * ld, f[r]);
+      for (int r = 0; r < 8; ++r) load8<T, NT>(base + (size_t)(t + 4 * r) * ld, f[r]);
 #pragma unroll
       for (int r = 0; r < 8; r += 4)
 #pragma unroll
@@ -212,16 +193,16 @@ __global__ __launch_bounds__(256) void act_l2_norms_kernel(const T* __restrict__
     }
     for (; t + 12 < t_end; t += 16) {
       float f0[8], f1[8], f2[8], f3[8];
-      load8<T>(base + (size_t)t * ld, f0);
-      load8<T>(base + (size_t)(t + 4) * ld, f1);
-      load8<T>(base + (size_t)(t + 8) * ld, f2);
-      load8<T>(base + (size_t)(t + 12) * ld, f3);
+      load8<T, NT>(base + (size_t)t * ld, f0);
+      load8<T, NT>(base + (size_t)(t + 4) * ld, f1);
+      load8<T, NT>(base + (size_t)(t + 8) * ld, f2);
+      load8<T, NT>(base + (size_t)(t + 12) * ld, f3);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += f0[k] * f0[k] + f1[k] * f1[k] + f2[k] * f2[k] + f3[k] * f3[k];
     }
     for (; t < t_end; t += 4) {
       float f0[8];
-      load8<T>(base + (size_t)t * ld, f0);
+      load8<T, NT>(base + (size_t)t * ld, f0);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += f0[k] * f0[k];
     }

@@ -1,6 +1,7 @@
 // Standalone micro-benchmark of gemm_bf16_kernel<EPI> on random bf16 data (HIP events, median of rounds).
 //   gemm_bench.bin M N K epi [iters] [tokens]       epi: 0 bf16, 1 resid, 2 fc1(+score), 3 patch, 4 f32 (128x128 kernel);
 //   10/11/12 bf16/resid/fc1 on the persistent 256x256 kernel, 20/21/22 the same on its round-1 version (A/B),
+//   15 resid + fused LayerNorm of the finished row panels (N = 768 / 1024 / 1280; x vs the 128x128 kernel, h vs layernorm_bf16_kernel),
 //   40/41/42 the same on the four-wave kernel (gemm256w4.hip.h), 30..33 e4m3 operands (gemm256 F8)
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -10,6 +11,7 @@
 #include <cstring>
 #include <vector>
 #include "../gemm256.hip.h"
+#include "../misc.hip.h"
 #include "gemm256w4.hip.h"
 #include "gemm256_v1.hip.h"
 
@@ -46,6 +48,12 @@ template <int EPI, int SCORE = 0> static void launch256(GemmArgs g, hipStream_t 
   if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS)); done = true; }
   g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
   hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(512), G256::LDS, s, g);
+}
+template <int LNV> static void launch256ln(GemmArgs g, hipStream_t s) {   // residual + LayerNorm of the finished panels: one workgroup per row panel
+  static bool done = false;
+  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI_RESID, LNV>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS)); done = true; }
+  g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
+  hipLaunchKernelGGL((gemm256_bf16_kernel<EPI_RESID, LNV>), dim3(std::min(g.tiles_m, nCU)), dim3(512), G256::LDS, s, g);
 }
 template <int EPI> static void launch256w4(GemmArgs g, hipStream_t s) {   // four-wave kernel (one wave per SIMD, 128 x 128 per wave)
   static bool done = false;
@@ -153,9 +161,20 @@ int main(int argc, char** argv) {
   unsigned long long* stamps; CK(hipMalloc(&stamps, (size_t)g.tiles_m * g.tiles_n * 64 * 8)); CK(hipMemset(stamps, 0, (size_t)g.tiles_m * g.tiles_n * 64 * 8));
   g.stamps = stamps;
 #endif
+  bf16 *h = nullptr, *h_ref = nullptr; float *lng = nullptr, *lnb = nullptr;
+  if (epi == 15) {
+    if (N % 256 || N / 256 < 3 || N / 256 > 5) { printf("epi 15 needs N = 768, 1024 or 1280\n"); return 1; }
+    std::vector<float> hg(N), hb(N);
+    for (int i = 0; i < N; ++i) { hg[i] = 0.5f + (rand() / (float)RAND_MAX); hb[i] = (rand() / (float)RAND_MAX) - 0.5f; }
+    CK(hipMalloc(&h, (size_t)(M + 2) * N * 2)); CK(hipMalloc(&h_ref, (size_t)(M + 2) * N * 2)); CK(hipMalloc(&lng, N * 4)); CK(hipMalloc(&lnb, N * 4));
+    CK(hipMemcpy(lng, hg.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(lnb, hb.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(h, 0, (size_t)(M + 2) * N * 2)); CK(hipMemset(h_ref, 0, (size_t)(M + 2) * N * 2));
+    g.ln_g = lng; g.ln_b = lnb; g.ln_out = h; g.ln_ld = N; g.ln_eps = 1e-6f;
+  }
   hipStream_t s; CK(hipStreamCreate(&s));
   auto run = [&]() {
-    switch (epi) { case 0: launch<EPI_BF16>(g, s); break; case 1: launch<EPI_RESID>(g, s); break; case 2: launch<EPI_FC1, 1>(g, s); break; case 5: launch<EPI_FC1, 2>(g, s); break; case 6: launch<EPI_FC1, 0>(g, s); break;
+    switch (epi) { case 15: if (N == 768) launch256ln<3>(g, s); else if (N == 1024) launch256ln<4>(g, s); else launch256ln<5>(g, s); break;
+                   case 0: launch<EPI_BF16>(g, s); break; case 1: launch<EPI_RESID>(g, s); break; case 2: launch<EPI_FC1, 1>(g, s); break; case 5: launch<EPI_FC1, 2>(g, s); break; case 6: launch<EPI_FC1, 0>(g, s); break;
                    case 3: launch<EPI_PATCH>(g, s); break; case 4: launch<EPI_F32>(g, s); break;
                    case 10: launch256<EPI_BF16>(g, s); break; case 11: launch256<EPI_RESID>(g, s); break;
                    case 12: launch256<EPI_FC1>(g, s); break; case 13: launch256<EPI_FC1, 1>(g, s); break; case 14: launch256<EPI_FC1, 2>(g, s); break;
@@ -165,7 +184,7 @@ int main(int argc, char** argv) {
                    default: break; }
   };
   if (epi >= 10) {   // verify the large-tile kernel against the (oracle-validated) 128x128 kernel, bit for bit
-    const bool resid = (epi % 10) == 1, fc1 = (epi % 10) == 2, sc1 = epi == 13, sc2 = epi == 14;
+    const bool resid = (epi % 10) == 1 || epi == 15, fc1 = (epi % 10) == 2, sc1 = epi == 13, sc2 = epi == 14;
     const size_t se = (size_t)((M + 127) / 128) * 2 * Npad;
     std::vector<float> slab_ref(se);
     size_t xe = (size_t)(M + M / 196 + 2) * Npad, oe = (size_t)M * Npad;
@@ -205,6 +224,52 @@ int main(int argc, char** argv) {
       printf("  mismatches by (row / 256) %% 16:"); for (int i = 0; i < 16; ++i) printf(" %ld", ht[i]); printf("\n");
     }
     printf("verify vs 128x128 kernel: %zu mismatching elements%s\n", bad, bad ? "  <-- FAIL" : " (bit-identical)");
+    if (epi == 15) {   // h of the fused phase vs the standalone LayerNorm kernel on the x the GEMM left behind
+      const int V = N / 256;
+      dim3 grid((M + 3) / 4), blk(256);
+      if (V == 3) hipLaunchKernelGGL(layernorm_bf16_kernel<3>, grid, blk, 0, s, x, (size_t)Npad, lng, lnb, h_ref, N, M, N, 1e-6f, RowMap{0, 0, 0}, (uint8_t*)nullptr);
+      else if (V == 4) hipLaunchKernelGGL(layernorm_bf16_kernel<4>, grid, blk, 0, s, x, (size_t)Npad, lng, lnb, h_ref, N, M, N, 1e-6f, RowMap{0, 0, 0}, (uint8_t*)nullptr);
+      else hipLaunchKernelGGL(layernorm_bf16_kernel<5>, grid, blk, 0, s, x, (size_t)Npad, lng, lnb, h_ref, N, M, N, 1e-6f, RowMap{0, 0, 0}, (uint8_t*)nullptr);
+      CK(hipStreamSynchronize(s));
+      std::vector<uint16_t> a((size_t)(M + 2) * N), b((size_t)(M + 2) * N);
+      CK(hipMemcpy(a.data(), h, a.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), h_ref, b.size() * 2, hipMemcpyDeviceToHost));
+      size_t hb = 0, nz = 0; for (size_t i = 0; i < a.size(); ++i) { if (a[i] != b[i]) { if (hb < 8) printf("  h[%zu][%zu] = %04x vs %04x\n", i / N, i % N, a[i], b[i]); ++hb; } nz += a[i] != 0; }
+      printf("fused LayerNorm vs layernorm_bf16_kernel: %zu mismatching of %zu (%zu non-zero)%s\n", hb, a.size(), nz, (hb || !nz) ? "  <-- FAIL" : " (bit-identical, rows past M untouched)");
+      bad += hb + (nz ? 0 : 1);
+      {   // ... and both against a host LayerNorm in double on a sample of rows (one bf16 rounding + fp32 arithmetic)
+        std::vector<float> hx((size_t)M * Npad), hg(N), hbt(N);
+        CK(hipMemcpy(hx.data(), x, hx.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hg.data(), lng, N * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hbt.data(), lnb, N * 4, hipMemcpyDeviceToHost));
+        size_t off = 0, chk = 0;
+        for (int m = 0; m < M; m += (m < 600 || m > M - 600) ? 1 : 211) {
+          double mu = 0, var = 0;
+          for (int c = 0; c < N; ++c) mu += hx[(size_t)m * Npad + c];
+          mu /= N;
+          for (int c = 0; c < N; ++c) { const double d = hx[(size_t)m * Npad + c] - mu; var += d * d; }
+          const double rstd = 1.0 / sqrt(var / N + 1e-6);
+          for (int c = 0; c < N; ++c) {
+            const double ref = (hx[(size_t)m * Npad + c] - mu) * rstd * hg[c] + hbt[c];
+            const double got = bf2f(a[(size_t)m * N + c]);
+            ++chk;
+            if (fabs(got - ref) > fabs(ref) * 0.0040 + 2e-5) { if (off < 8) printf("  h[%d][%d] = %g, host %g\n", m, c, got, ref); ++off; }
+          }
+        }
+        printf("fused LayerNorm vs host double: %zu of %zu sampled elements outside one bf16 rounding%s\n", off, chk, off ? "  <-- FAIL" : " (ok)");
+        bad += off;
+      }
+      {   // what the fused phase replaces: the standalone kernel over the same rows
+        const int V2 = N / 256; dim3 grid2((M + 3) / 4), blk2(256);
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); float best = 1e9f;
+        for (int it = 0; it < 7; ++it) {
+          CK(hipEventRecord(e0, s));
+          if (V2 == 3) hipLaunchKernelGGL(layernorm_bf16_kernel<3>, grid2, blk2, 0, s, x, (size_t)Npad, lng, lnb, h_ref, N, M, N, 1e-6f, RowMap{0, 0, 0}, (uint8_t*)nullptr);
+          else if (V2 == 4) hipLaunchKernelGGL(layernorm_bf16_kernel<4>, grid2, blk2, 0, s, x, (size_t)Npad, lng, lnb, h_ref, N, M, N, 1e-6f, RowMap{0, 0, 0}, (uint8_t*)nullptr);
+          else hipLaunchKernelGGL(layernorm_bf16_kernel<5>, grid2, blk2, 0, s, x, (size_t)Npad, lng, lnb, h_ref, N, M, N, 1e-6f, RowMap{0, 0, 0}, (uint8_t*)nullptr);
+          CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); float t; CK(hipEventElapsedTime(&t, e0, e1)); best = std::min(best, t);
+        }
+        printf("standalone layernorm_bf16_kernel over the same %d rows: %.1f us\n", M, best * 1e3);
+      }
+      CK(hipMemset(h, 0, a.size() * 2));
+    }
     CK(hipMemset(x, 0, xe * 4));
   }
   if (const char* st = getenv("GEMM_STRESS")) {   // race screen: many launches, every result compared with the first

@@ -35,6 +35,7 @@ VIT_CONFIGS = {
     # the reference's own smoke-test config (experiments/vit_pruning/test_stage2_attention_only.py:44-53)
     "vit_test_patch16_32": (32, 16, 64, 4, 128, 4),
     # two-block cuts of the large geometries (same kernels / tile shapes as the full models, test-sized)
+    "vit_base_patch16_224_d3": (224, 16, 768, 12, 3072, 3),
     "vit_large_patch16_224_d2": (224, 16, 1024, 16, 4096, 2),
     "vit_huge_patch14_224_d2": (224, 14, 1280, 16, 5120, 2),
     "vit_small_patch16_224_d2": (224, 16, 384, 6, 1536, 2),

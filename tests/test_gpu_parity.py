@@ -1049,3 +1049,42 @@ def test_fp8_engine_tracks_the_bf16_engine_within_the_e4m3_tolerance(gpu, cfg):
     # determinism of the fp8 path itself
     assert torch.equal(f8.forward_logits(px).cpu(), l8)
     ref.close(); f8.close()
+
+
+@pytest.mark.parametrize("cfg,precision", [("vit_base_patch16_224_d3", "bf16"), ("vit_large_patch16_224_d2", "bf16"),
+                                           ("vit_huge_patch14_224_d2", "bf16"), ("vit_base_patch16_224_d3", "fp8")])
+def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_bits(gpu, cfg, precision, monkeypatch):
+    """SSP2_LN_FUSION (opt-in, csrc/engine.hip ln_fusable): the attention out-projection and fc2 of a launch with >= 4096
+    rows normalise the row panels they finish inside the GEMM kernel (gemm256.hip.h, LNV = dim / 256 = 3, 4, 5; one workgroup
+    per 256-row panel) instead of launching layernorm_bf16_kernel.  Both call ONE row routine (ln_row_finish), so logits,
+    and stage-1 scores must be the same bits — with the attention of a middle block skipped (fc2 then hands
+    LN2 of the next block over, not LN1), with a row count that is not a multiple of 256, and on e4m3 operands (the
+    phase then writes the e4m3 bytes).  '2' forces the fused form for every eligible launch (no cost model)."""
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights(cfg, classes=10, seed=5, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
+    depth = int(w["depth"])
+    eng = VitEngine(w, max_images=40, precision=precision)
+    g = torch.Generator().manual_seed(9)
+    px = torch.randn(40, 3, 224, 224, generator=g).to(gpu)             # 40 x 197 = 7880 / 40 x 257 = 10280 rows: a ragged last panel
+    skips = [None] + ([[1]] if depth > 2 else []) + [[0], [depth - 1]]
+    def run():
+        out = []
+        for sk in skips:
+            out.append(eng.forward_logits(px, attn_skip=sk).cpu())
+        for site in ("pre_gelu", "post_gelu"):
+            out.append(eng.forward_scores(px, site)[0].cpu())
+        return out
+    monkeypatch.delenv("SSP2_LN_FUSION", raising=False)
+    plain = run()
+    monkeypatch.setenv("SSP2_LN_FUSION", "2")
+    fused = run()
+    for a, b in zip(plain, fused):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b)
+            assert bool(torch.isfinite(a).all())
+        else:
+            assert a == b
+    monkeypatch.setenv("SSP2_LN_FUSION", "1")                           # the cost model's choice: same bits again
+    for a, b in zip(plain, run()):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
