@@ -94,9 +94,8 @@ __device__ __forceinline__ uint32_t pack_e4m3x4_from(float a, float b, float c, 
 // The row statistics are wave-uniform values computed on the VALU of every lane, so their cost is per row, not per
 // element: sum * (1 / D) instead of a division, v_rsq_f32 + one Newton step instead of 1 / sqrt (both within 1 ulp of the
 // correctly rounded forms: 12 + 27 instructions of ~130 per row saved, which matters where the VALU is the bound — the GEMM's phase).
-template <int MAXV, bool FULL, bool OUT8>
-__device__ __forceinline__ void ln_row_finish(const f32x4 (&v)[MAXV], int lane, int nv, float inv_d, float eps, const f32x4 (&g4)[MAXV],
-                                              const f32x4 (&b4)[MAXV], void* y) {
+template <int MAXV, bool FULL>
+__device__ __forceinline__ void ln_row_stats(const f32x4 (&v)[MAXV], int lane, int nv, float inv_d, float eps, float& mean, float& rstd) {
   // no contraction beyond the fmas written out below: left to hipcc, ONE of the four instances (the GEMM phase's e4m3 form)
   // folded mean = sum * inv_d into the subtractions, v - sum * inv_d as one fma, and a few e4m3 bytes per launch differed
 #pragma clang fp contract(off)
@@ -104,7 +103,7 @@ __device__ __forceinline__ void ln_row_finish(const f32x4 (&v)[MAXV], int lane, 
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
     if (FULL || i * 64 + lane < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-  const float mean = wave_sum_dpp(s) * inv_d;
+  mean = wave_sum_dpp(s) * inv_d;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
@@ -113,19 +112,27 @@ __device__ __forceinline__ void ln_row_finish(const f32x4 (&v)[MAXV], int lane, 
       for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mean; q = __builtin_fmaf(d, d, q); }
     }
   const float var = __builtin_fmaf(wave_sum_dpp(q), inv_d, eps);
-  float rstd = __builtin_amdgcn_rsqf(var);
+  rstd = __builtin_amdgcn_rsqf(var);
   rstd = rstd * __builtin_fmaf(-0.5f * var * rstd, rstd, 1.5f);           // one Newton step on v_rsq_f32's 1-ulp estimate
+}
+// chunk i of the row: ((v - mean) * rstd) * gamma + beta, bf16-rounded, stored as bf16 or as the e4m3 bytes of the bf16 values
+template <bool OUT8>
+__device__ __forceinline__ void ln_chunk_write(const f32x4& v, float mean, float rstd, const f32x4& g4, const f32x4& b4, void* y, int c) {
+#pragma clang fp contract(off)
+  bf16x4 o;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = i * 64 + lane;
-    if (FULL || c < nv) {
-      bf16x4 o;
+  for (int k = 0; k < 4; ++k) o[k] = (bf16)__builtin_fmaf((v[k] - mean) * rstd, g4[k], b4[k]);
+  if constexpr (OUT8) *(uint32_t*)((uint8_t*)y + c * 4) = pack_e4m3x4_from((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+  else *(bf16x4*)((bf16*)y + c * 4) = o;
+}
+template <int MAXV, bool FULL, bool OUT8>
+__device__ __forceinline__ void ln_row_finish(const f32x4 (&v)[MAXV], int lane, int nv, float inv_d, float eps, const f32x4 (&g4)[MAXV],
+                                              const f32x4 (&b4)[MAXV], void* y) {
+  float mean, rstd;
+  ln_row_stats<MAXV, FULL>(v, lane, nv, inv_d, eps, mean, rstd);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = (bf16)__builtin_fmaf((v[i][k] - mean) * rstd, g4[i][k], b4[i][k]);
-      if constexpr (OUT8) *(uint32_t*)((uint8_t*)y + c * 4) = pack_e4m3x4_from((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
-      else *(bf16x4*)((bf16*)y + c * 4) = o;
-    }
-  }
+  for (int i = 0; i < MAXV; ++i)
+    if (FULL || i * 64 + lane < nv) ln_chunk_write<OUT8>(v[i], mean, rstd, g4[i], b4[i], y, i * 64 + lane);
 }
 
 // XCD-aware bijective remap of a 1-D grid (blocks b and b+8 share an XCD): each XCD walks a contiguous

@@ -60,16 +60,24 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   // gather.tokens > 0: output row r is the CLS row of image r (slab layout aware); else input row r*in_stride
   const f32x4* xr = (const f32x4*)(gather.tokens > 0 ? x + (size_t)row_of(gather, row) * D : x + (size_t)row * in_stride);
   const int nv = D >> 2;                      // float4 chunks in the row
-  f32x4 v[MAXV], g4[MAXV], b4[MAXV];
+  f32x4 v[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i * 64 + lane < nv) v[i] = xr[i * 64 + lane];
+  float mean, rstd;
+  ln_row_stats<MAXV, false>(v, lane, nv, 1.0f / (float)D, eps, mean, rstd);
+  // gamma / beta only now (L2 hits): held across the statistics they cost 24 registers per wave and three of its eight
+  // waves per SIMD — the kernel lives on memory-level parallelism (84 VGPRs: 60 us for 63040 rows, 32: 50 us)
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = i * 64 + lane;
-    if (c < nv) { v[i] = xr[c]; g4[i] = ((const f32x4*)gamma)[c]; b4[i] = ((const f32x4*)beta)[c]; }
+    if (c < nv) {
+      const f32x4 g4 = ((const f32x4*)gamma)[c], b4 = ((const f32x4*)beta)[c];
+      // fp8 mode: e4m3 bytes (of the bf16-rounded value), out_ld in bytes
+      if (y8) ln_chunk_write<true>(v[i], mean, rstd, g4, b4, y8 + (size_t)row * out_ld, c);
+      else    ln_chunk_write<false>(v[i], mean, rstd, g4, b4, y + (size_t)row * out_ld, c);
+    }
   }
-  // fp8 mode: e4m3 bytes (of the bf16-rounded value), out_ld in bytes
-  const float inv_d = 1.0f / (float)D;
-  if (y8) ln_row_finish<MAXV, false, true>(v, lane, nv, inv_d, eps, g4, b4, y8 + (size_t)row * out_ld);
-  else    ln_row_finish<MAXV, false, false>(v, lane, nv, inv_d, eps, g4, b4, y + (size_t)row * out_ld);
 }
 
 // ------------------------------------------------------------------------------------------------
