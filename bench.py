@@ -224,7 +224,12 @@ def main():
                     help="run stage 1 and a share of the search candidates on a second HIP stream with its own engine "
                          "workspace (per-launch durations then include the share of the machine lent to the other stream, "
                          "so the roofline object is not a clean kernel figure)")
+    ap.add_argument("--overlap-stage1", action="store_true",
+                    help="stage 1 on a second HIP stream (own engine workspace) BESIDE the layer-major search on the main one; "
+                         "unlike --two-streams the search keeps its layer-major form and its candidates are not shared out")
     args = ap.parse_args()
+    if args.overlap_stage1 and args.two_streams:
+        raise SystemExit("--overlap-stage1 and --two-streams are two forms of the same idea: pick one")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -282,8 +287,9 @@ def main():
     # are the search candidates: with a second engine workspace (weights uploaded twice, 173 MB) on a second HIP stream
     # the memory-bound kernels of one stream (LayerNorm, attention, epilogue tails) overlap the matrix-bound kernels of
     # the other and the partial last round of a persistent GEMM is filled by the other stream's workgroups.
-    eng1 = VitEngine(weights, device=dev, max_images=max(args.batch, calib_chunk), precision=args.precision) if args.two_streams else eng
-    side = torch.cuda.Stream(dev) if args.two_streams else None
+    second = args.two_streams or args.overlap_stage1
+    eng1 = VitEngine(weights, device=dev, max_images=max(args.batch, calib_chunk), precision=args.precision) if second else eng
+    side = torch.cuda.Stream(dev) if second else None
     d_ints = [d_int] * depth
     twins = [eng.pruned_twin([d_int - p.per_block_neurons_to_prune] * depth, max_images=args.batch) for p in plans]
 
@@ -342,9 +348,9 @@ def main():
         # work expressed in block passes of the search chunk)
         search = core.depth_search_counts(eng, eval_loader, depth, batch_limit=None, process_group=pg,
                                           chunk_images=eval_chunk, defer=True,
-                                          aux_engine=None if side is None else eng1, aux_stream=side,
+                                          aux_engine=eng1 if args.two_streams else None, aux_stream=side if args.two_streams else None,
                                           aux_lead=n_calib * depth / max(1, eval_chunk),
-                                          batch_candidates=args.batch_candidates and side is None, sharded=True)
+                                          batch_candidates=args.batch_candidates, sharded=True)
         imps = scores()
         all_masks = []
         for p in plans:                                                   # a7 mask step per target (host, 12 x 3072)
@@ -426,7 +432,7 @@ def main():
             "selected_blocks": out[3][targets.index(args.target)] if args.target in targets else out[3][0],
             "selected_blocks_per_target": {str(t): b for t, b in zip(targets, out[3])},
             "pruned_neurons_per_block": plan.per_block_neurons_to_prune,
-            "streams": 2 if args.two_streams else 1, "search": "layer-major" if args.batch_candidates else "candidate-major",
+            "streams": 2 if (args.two_streams or args.overlap_stage1) else 1, "stage1_beside_search": bool(args.overlap_stage1), "search": "layer-major" if args.batch_candidates else "candidate-major",
         }
         if coll is not None:
             line["collectives"] = {"backend": "nccl (RCCL)", "world_size": world,
