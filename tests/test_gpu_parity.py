@@ -606,12 +606,15 @@ def test_prune_masks_identical_to_oracle_where_the_cut_margin_allows(gpu):
 def test_persistent_gemm_edge_shapes_bitwise_vs_small_tile_kernel(gpu):
     """csrc/tools/gemm_bench bit-compares the persistent 256x256 GEMM with the 128x128 kernel (itself checked against
     the oracle above) on random data: K of one / two / three K-tiles, partial row and column tiles, every epilogue
-    incl. both scoring variants (output AND slab) and the residual epilogue (nothing written past row M)."""
+    incl. both scoring variants (output AND slab) and the residual epilogue (nothing written past row M); the residual +
+    LayerNorm-phase form on ragged panels, one K-tile, more panels than CUs (66000 rows) and the three row widths."""
     import subprocess
     from ssp2vit import _lib
     exe = _lib.build_tool("gemm_bench")       # rebuilt whenever the tool OR any kernel header differs from the binary's hash
     for shape in ("8192 128 64 10", "8192 128 64 11", "8192 128 64 12", "8200 64 128 11", "9000 192 192 13",
-                  "9001 320 192 14", "5000 2304 768 10", "4100 1984 768 13", "6000 768 1984 11", "12608 768 3072 11"):
+                  "9001 320 192 14", "5000 2304 768 10", "4100 1984 768 13", "6000 768 1984 11", "12608 768 3072 11",
+                  # 15: residual + the opt-in LayerNorm phase (x vs the 128x128 kernel, h vs layernorm_bf16_kernel AND a host double)
+                  "5000 768 768 15", "300 768 64 15", "66000 768 128 15", "4100 1024 1024 15", "2571 1280 320 15"):
         out = subprocess.run([exe] + shape.split() + ["2"], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "bit-identical" in out.stdout and "FAIL" not in out.stdout, f"{shape}: {out.stdout}"
