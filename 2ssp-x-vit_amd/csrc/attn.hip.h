@@ -332,7 +332,8 @@ __device__ unsigned long long* attn_stamp_ptr;    // [8 waves][256 slots] of wor
 
 template <int NT>
 __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
-                                                               int tokens, int dim, int heads, int n_items, float scale, RowMap rm) {
+                                                               int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
+                                                               int reverse = 0) {
   static_assert(NT >= 1 && NT <= 7, "one consumer wave per query tile, wave 7 produces");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = 4, DT = 2, NKEY = NT * 32, KV = NKEY * 128, BUF = 2 * KV;
@@ -341,7 +342,8 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
   const int l31 = lane & 31, lh = lane >> 5;
   const int G = gridDim.x;
 
-  auto row0_of = [&](int it, int& head) -> size_t { const int img = it / heads; head = it - img * heads; return (size_t)row_of(rm, img); };
+  // reverse: the items are walked from the last image to the first (engine.hip, zigzag launch order)
+  auto row0_of = [&](int it, int& head) -> size_t { if (reverse) it = n_items - 1 - it; const int img = it / heads; head = it - img * heads; return (size_t)row_of(rm, img); };
 
   // ---- producer side
   auto issue = [&](int it, int b) {

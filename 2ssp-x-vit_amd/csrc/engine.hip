@@ -92,6 +92,7 @@ struct ssp2_engine {
   long rows_cap = 0;        // token-matrix rows the workspace is sized for
   hipStream_t stream = nullptr;
   int n_cu = 256;
+  int zig = 0;             // direction of the next large launch (next_dir)
   std::vector<void*> allocs;
   size_t ws_bytes = 0, weight_bytes = 0;
 
@@ -143,6 +144,18 @@ static int mat_alloc(ssp2_engine* e, Mat& m, int rows, int cols) {
   return 0;
 }
 
+// Zigzag launch order: every large launch (persistent GEMM, LayerNorm, persistent attention) walks its row panels in the
+// direction opposite to the previous launch's, so it starts on the rows its producer wrote LAST — the ones still in the
+// 256 MiB Infinity Cache — instead of on the oldest, which its own traffic would evict before it gets to the fresh ones
+// (the streaming pathology of an LRU cache smaller than the tensor: 194 MB of x, 290 MB of qkv, 387 MB of activations per
+// 320 images).  Results do not depend on the order.  Same-box A/B, three boxes: -0.8 % of the step
+// (profiles/r02_f_zigzag_ab.txt); SSP2_ZIGZAG=0 switches it off.
+static int next_dir(ssp2_engine* e) {
+  static const bool on = [] { const char* v = getenv("SSP2_ZIGZAG"); return !v || v[0] != '0'; }();
+  if (!on) return 0;
+  const int d = e->zig; e->zig ^= 1; return d;
+}
+
 struct ProfScope {
   ssp2_engine* e; bool on; hipEvent_t a{}, b{};
   ProfScope(ssp2_engine* e_, int klass, double flops = 0) : e(e_), on(e_->prof_class == klass) {
@@ -168,6 +181,7 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
     HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS));
     attr_done = true;
   }
+  if (!(EPI == EPI_RESID && SCORE > 0)) g.reverse = next_dir(e);
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
   // EPI_RESID with SCORE > 0 = LayerNorm fused behind the epilogue: one workgroup per ROW PANEL (it owns all its column tiles)
   const int wgs = (EPI == EPI_RESID && SCORE > 0) ? std::min(g.tiles_m, e->n_cu) : std::min(g.tiles_m * g.tiles_n, e->n_cu);
@@ -246,7 +260,8 @@ static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const flo
   dim3 grid((rows + 3) / 4), blk(256);
   // one instantiation per row width in 256-element steps: the row lives in MAXV float4 registers per lane, and a
   // wider instantiation than needed drags predicated dead chunks along (ViT-L/16 on <8>: 3.1 TB/s; on <4>: see DESIGN)
-#define LN_CASE(V) hipLaunchKernelGGL(layernorm_bf16_kernel<V>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8)
+  const int rev = rows >= kBigTileMinRows ? next_dir(e) : 0;
+#define LN_CASE(V) hipLaunchKernelGGL(layernorm_bf16_kernel<V>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8, rev)
   if (D <= 256 * 1) LN_CASE(1);
   else if (D <= 256 * 2) LN_CASE(2);
   else if (D <= 256 * 3) LN_CASE(3);
@@ -286,8 +301,9 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
       }
       const long items = (long)e->d.heads * n;
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
+      const int rev = next_dir(e);
       hipLaunchKernelGGL((attn64_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
-                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm);
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev);
       HIPCHK(hipGetLastError());
       return 0;
     }

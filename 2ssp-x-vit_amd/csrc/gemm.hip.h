@@ -52,6 +52,7 @@ struct GemmArgs {
   // EPI_PATCH
   const float* pos; int patches;
   int group_m;                // row tiles per L2 super-tile (0 = plain N-fastest order)
+  int reverse;                // gemm256: walk the tiles from the last to the first (see engine.hip, zigzag)
   // fp8 (e4m3) operands, gemm256 kernel with F8 = true only: A and W point at BYTES (lda / ldw / K count fp8 elements,
   // K a multiple of 128), acc is multiplied by wscale[n] (the weight row's dequantisation scale) before the bias;
   // EPI_FC1 then writes e4m3 bytes to `out` (ldo in bytes) for the fp8 fc2 that follows

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   float wsc_next = 1.f;                                 // F8: wscale[...] of the same column
   auto set_tile = [&](int tile) {
     int tm, tn;
+    if (g.reverse) tile = ntiles - 1 - tile;
     const int gn = g.group_m % 100, gm = g.group_m / 100;          // group_m = 100 * GM + GN (0: plain order)
     if (gn > 0 && gn < g.tiles_n) {
       // Super-tiles for the 4 MiB L2 of an XCD: blocks of GM row panels (all of them if GM = 0); inside a block column

@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16* __restrict__ y,
                                                             int out_ld, int rows, int D, float eps, RowMap gather,
-                                                            uint8_t* __restrict__ y8 = nullptr) {
+                                                            uint8_t* __restrict__ y8 = nullptr, int reverse = 0) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = (reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   // gather.tokens > 0: output row r is the CLS row of image r (slab layout aware); else input row r*in_stride
   const f32x4* xr = (const f32x4*)(gather.tokens > 0 ? x + (size_t)row_of(gather, row) * D : x + (size_t)row * in_stride);
