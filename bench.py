@@ -333,22 +333,22 @@ def main():
 
     sdist.TIMING = args.config == 2 and pg is not None
 
-    def step():
+    def step(s1_eng=eng1, sd=side, share=args.two_streams):
         # both stages are enqueued before the host waits for either: the a7 mask step runs on the CPU while the GPU
         # is still searching (the two stages are independent: stage 2 evaluates the dense model)
-        if side is None:
-            scores = core.stage1_scores(eng1, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
+        if sd is None:
+            scores = core.stage1_scores(s1_eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
                                         chunk_images=calib_chunk, defer=True, sharded=True)
         else:
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                scores = core.stage1_scores(eng1, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
+            sd.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(sd):
+                scores = core.stage1_scores(s1_eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
                                             chunk_images=calib_chunk, defer=True, sharded=True)
         # the side stream also takes a share of the search candidates behind its stage-1 launch (lead ~ the stage-1
         # work expressed in block passes of the search chunk)
         search = core.depth_search_counts(eng, eval_loader, depth, batch_limit=None, process_group=pg,
                                           chunk_images=eval_chunk, defer=True,
-                                          aux_engine=eng1 if args.two_streams else None, aux_stream=side if args.two_streams else None,
+                                          aux_engine=s1_eng if share else None, aux_stream=sd if share else None,
                                           aux_lead=n_calib * depth / max(1, eval_chunk),
                                           batch_candidates=args.batch_candidates, sharded=True)
         imps = scores()
@@ -363,8 +363,8 @@ def main():
             all_masks.append(masks)
         base, cand, total = search()
         impact = torch.tensor(core.impacts_from_counts(base, cand, total), dtype=torch.float32)
-        if side is not None:
-            torch.cuda.current_stream(dev).wait_stream(side)
+        if sd is not None:
+            torch.cuda.current_stream(dev).wait_stream(sd)
         chosen = []
         for p, masks, twin in zip(plans, all_masks, twins):
             blocks = sorted(int(i) for i in torch.argsort(impact)[: p.blocks_to_prune])   # a9 (auto_2ssp.py:857)
@@ -398,6 +398,21 @@ def main():
     sync_all(); t1 = time.perf_counter()
     core.stage1_scores(eng1, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg, chunk_images=calib_chunk, sharded=True)
     sync_all(); s1_s = time.perf_counter() - t1
+
+    # secondary figure: the same step with stage 1 on a second HIP stream (own engine workspace) beside the layer-major search —
+    # the two stages are independent.  Not the headline: kernels of two streams share the CUs, so per-launch durations (the
+    # roofline object) are not clean kernel figures in such a run.
+    overlap = None
+    if world == 1 and args.config == 1 and not second and not args.no_roofline:
+        e2 = VitEngine(weights, device=dev, max_images=max(args.batch, calib_chunk), precision=args.precision)
+        st2 = torch.cuda.Stream(dev)
+        step(e2, st2, False); sync_all()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            o2 = step(e2, st2, False)
+        sync_all()
+        overlap = (time.perf_counter() - t2, o2[3])
+        e2.close()
 
     el = torch.tensor([elapsed, s1_s], dtype=torch.float64, device=dev)
     if pg is not None:
@@ -434,6 +449,10 @@ def main():
             "pruned_neurons_per_block": plan.per_block_neurons_to_prune,
             "streams": 2 if (args.two_streams or args.overlap_stage1) else 1, "stage1_beside_search": bool(args.overlap_stage1), "search": "layer-major" if args.batch_candidates else "candidate-major",
         }
+        if overlap is not None:
+            line["stage1_beside_search"] = {"ms_per_step": round(1e3 * overlap[0] / args.steps, 2), "value": round(units_step * args.steps / overlap[0], 1),
+                                            "streams": 2, "same_selection": overlap[1] == out[3],
+                                            "note": "stage 1 on a second HIP stream with its own engine workspace beside the layer-major search; secondary figure (bench.py --overlap-stage1 makes it the timed region)"}
         if coll is not None:
             line["collectives"] = {"backend": "nccl (RCCL)", "world_size": world,
                                    "device_ms_per_step": {k: round(v / args.steps, 3) for k, v in coll.items()}}
