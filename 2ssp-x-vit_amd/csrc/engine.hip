@@ -151,8 +151,8 @@ static int mat_alloc(ssp2_engine* e, Mat& m, int rows, int cols) {
 // 320 images).  Results do not depend on the order.  Same-box A/B, three boxes: -0.8 % of the step
 // (profiles/r02_f_zigzag_ab.txt); SSP2_ZIGZAG=0 switches it off.
 static int next_dir(ssp2_engine* e) {
-  static const bool on = [] { const char* v = getenv("SSP2_ZIGZAG"); return !v || v[0] != '0'; }();
-  if (!on) return 0;
+  const char* v = getenv("SSP2_ZIGZAG");                       // read per launch: the GPU test flips it inside one process
+  if (v && v[0] == '0') return 0;
   const int d = e->zig; e->zig ^= 1; return d;
 }
 

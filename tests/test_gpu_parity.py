@@ -1091,3 +1091,32 @@ def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_
     monkeypatch.setenv("SSP2_LN_FUSION", "1")                           # the cost model's choice: same bits again
     for a, b in zip(plain, run()):
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+
+
+def test_zigzag_launch_order_does_not_change_a_bit(gpu, monkeypatch):
+    """csrc/engine.hip next_dir: every large launch (persistent GEMM, LayerNorm, persistent attention) walks its row panels
+    opposite to the previous one, so that it starts on what its producer wrote last (Infinity Cache).  The order never enters
+    a result: logits, both score sites and a search's counts with SSP2_ZIGZAG=0 (every launch ascending) are the same bits;
+    two consecutive default runs (which start in opposite directions) too."""
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_base_patch16_224_d3", classes=10, seed=6, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
+    eng = VitEngine(w, max_images=3 * 40)
+    g = torch.Generator().manual_seed(12)
+    px = torch.randn(40, 3, 224, 224, generator=g).to(gpu)             # 7880 rows: persistent kernels, a ragged last panel
+    labels = torch.randint(0, 10, (40,), generator=g).to(gpu)
+    loader = [{"pixel_values": px, "labels": labels}]
+    def run():
+        out = [eng.forward_logits(px).cpu(), eng.forward_logits(px, attn_skip=[1]).cpu()]
+        out += [eng.forward_scores(px, s)[0].cpu() for s in ("pre_gelu", "post_gelu")]
+        base, cand, total = core.depth_search_counts(eng, loader, 3, batch_limit=None, chunk_images=40)
+        return out, (base, list(cand), total)
+    monkeypatch.delenv("SSP2_ZIGZAG", raising=False)
+    a, ca = run()
+    b, cb = run()
+    monkeypatch.setenv("SSP2_ZIGZAG", "0")
+    c, cc = run()
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    assert ca == cb == cc
