@@ -224,6 +224,8 @@ def main():
                     help="run stage 1 and a share of the search candidates on a second HIP stream with its own engine "
                          "workspace (per-launch durations then include the share of the machine lent to the other stream, "
                          "so the roofline object is not a clean kernel figure)")
+    ap.add_argument("--no-overlap-figure", action="store_true",
+                    help="skip the secondary two-stream figure (profiled runs: its kernels would be counted with the step's)")
     ap.add_argument("--overlap-stage1", action="store_true",
                     help="stage 1 on a second HIP stream (own engine workspace) BESIDE the layer-major search on the main one; "
                          "unlike --two-streams the search keeps its layer-major form and its candidates are not shared out")
@@ -403,7 +405,7 @@ def main():
     # the two stages are independent.  Not the headline: kernels of two streams share the CUs, so per-launch durations (the
     # roofline object) are not clean kernel figures in such a run.
     overlap = None
-    if world == 1 and args.config == 1 and not second and not args.no_roofline:
+    if world == 1 and args.config == 1 and not second and not args.no_roofline and not args.no_overlap_figure:
         e2 = VitEngine(weights, device=dev, max_images=max(args.batch, calib_chunk), precision=args.precision)
         st2 = torch.cuda.Stream(dev)
         step(e2, st2, False); sync_all()

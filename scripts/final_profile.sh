@@ -14,7 +14,7 @@ python3 scripts/pmc_mfma.py $O/pmc_mfma > profiles/${TAG}_pmc_mfma.json 2>> $O/$
 timeout -k 10 300 bash scripts/pmc_act_l2.sh > $O/${TAG}_pmc_act_l2.log 2>&1; cp $O/pmc_act_l2.json profiles/${TAG}_pmc_act_l2.json; cp $O/pmc_act_l2.json $O/${TAG}_pmc_act_l2.json
 timeout -k 10 500 python3 bench.py > $O/${TAG}_bench.jsonl 2> $O/${TAG}_bench.err || exit 1
 cut -c1-300 $O/${TAG}_bench.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG} -- python3 bench.py --no-cpu-baseline --no-api > $O/${TAG}_bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG} -- python3 bench.py --no-cpu-baseline --no-api --no-overlap-figure > $O/${TAG}_bench_prof.log 2>&1
 cp $(ls -t $O/prof_${TAG}/*/*_kernel_stats.csv | head -1) $O/${TAG}_bench_kernel_stats.csv
 python3 scripts/trace_gaps.py $(ls -t $O/prof_${TAG}/*/*_kernel_trace.csv | head -1) --json $O/${TAG}_trace_gaps.json > /dev/null 2>&1
 for v in "--host-inputs" "--uint8" "--host-inputs --uint8" "--two-streams"; do
@@ -23,5 +23,5 @@ done
 timeout -k 10 400 python3 bench.py --config 2 --no-cpu-baseline --no-roofline --steps 2 > $O/${TAG}_bench_config2_n1.jsonl 2>> $O/${TAG}_bench_variants.err; echo "config2 rc=$?"
 for m in "vit_huge_patch14_224 0.5 bf16" "vit_huge_patch14_224 0.5 fp8" "vit_large_patch16_224 0.375 bf16" "vit_small_patch16_224 0.375 bf16"; do
   set -- $m
-  timeout -k 10 500 python3 bench.py --model $1 --target $2 --precision $3 --steps 2 --warmup 1 --no-api --no-cpu-baseline >> $O/${TAG}_other_models.jsonl 2>> $O/${TAG}_bench_variants.err; echo "$m rc=$?"
+  timeout -k 10 500 python3 bench.py --model $1 --target $2 --precision $3 --steps 2 --warmup 1 --no-api --no-cpu-baseline --no-overlap-figure >> $O/${TAG}_other_models.jsonl 2>> $O/${TAG}_bench_variants.err; echo "$m rc=$?"
 done
