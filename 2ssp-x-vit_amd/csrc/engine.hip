@@ -615,7 +615,10 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
   if ((rc = check_n(e, n, score_group))) return rc;
   if (!x) return fail(SSP2_EINVAL, "null x");
   if (l_begin < 0 || l_end > e->d.depth || l_begin > l_end) return fail(SSP2_EINVAL, "bad layer range [%d,%d)", l_begin, l_end);
+  const bool scores_only = (score_site & SSP2_SCORE_ONLY) != 0;
+  score_site &= ~SSP2_SCORE_ONLY;
   if (score_site < 0 || score_site > 2) return fail(SSP2_EINVAL, "bad score_site %d", score_site);
+  if (scores_only && !score_site) return fail(SSP2_EINVAL, "SSP2_SCORE_ONLY without a score site");
   if (score_site && (!batch_scores || score_ld < e->ld_int_max)) return fail(SSP2_EINVAL, "batch_scores needs ld >= %d", e->ld_int_max);
   const RowMap rm = make_rowmap(e->tokens, n, score_group);
   const int D = e->d.dim, M = (int)total_rows(rm, n);
@@ -707,6 +710,7 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
         if ((rc = act_l2_impl(e->stream, seen, 0, n, rm, L.d_int, L.ld_int, score_chain, grp, e->norms, row, group_stride))) return rc;
       }
     }
+    if (scores_only && l + 1 == l_end) break;            // nothing reads x behind the last hooked activation
     GemmArgs o{};
     o.bias = L.fc2.b; o.M = M; o.N = D; o.tiles_n = L.fc2.rows_pad / GEMM_BN; o.x = x; o.ldx = D;
     // + the LayerNorm the NEXT layer of this call starts with: LN1 of layer l + 1, or its LN2 when its attention is skipped

@@ -182,10 +182,11 @@ class VitEngine:
 
     def layers(self, x: torch.Tensor, n: int, l_begin: int = 0, l_end: Optional[int] = None,
                attn_skip: Optional[Sequence[int]] = None, score_site: str = "none", score_chain: str = "fp32",
-               batch_scores: Optional[torch.Tensor] = None, score_group: int = 0) -> Optional[torch.Tensor]:
-        """Returns f32 [groups, depth, score_ld] when scoring (groups = ceil(n / score_group), 1 if score_group=0)."""
+               batch_scores: Optional[torch.Tensor] = None, score_group: int = 0, scores_only: bool = False) -> Optional[torch.Tensor]:
+        """Returns f32 [groups, depth, score_ld] when scoring (groups = ceil(n / score_group), 1 if score_group=0).
+        `scores_only`: x is scratch afterwards — the last block stops behind its hooked activation (SSP2_SCORE_ONLY)."""
         l_end = self.depth if l_end is None else l_end
-        site = SCORE_SITE[score_site]
+        site = SCORE_SITE[score_site] | (0x10 if (scores_only and SCORE_SITE[score_site]) else 0)
         grp = n if (score_group <= 0 or score_group > n) else score_group
         if site and batch_scores is None:
             batch_scores = self.new_scores((n + grp - 1) // grp)
@@ -269,7 +270,7 @@ class VitEngine:
         if n > self.max_images:
             raise Ssp2Error(f"chunk of {n} images exceeds engine capacity {self.max_images}")
         x = self.embed(pixels, group=group)             # slab layout: one 256-row-aligned slab per batch
-        return self.layers(x, n, 0, self.depth, None, score_site, score_chain, None, group)
+        return self.layers(x, n, 0, self.depth, None, score_site, score_chain, None, group, scores_only=True)
 
     def forward_logits(self, pixels: torch.Tensor, attn_skip: Optional[Sequence[int]] = None) -> torch.Tensor:
         outs = []

@@ -44,6 +44,10 @@ enum {
 
 /* where the stage-1 score is read (reference hook site, src/vit_pruning.py:130 vs :135) */
 enum { SSP2_SCORE_NONE = 0, SSP2_SCORE_PRE_GELU = 1 /* timm: fc1 out */, SSP2_SCORE_POST_GELU = 2 /* HF: intermediate out */ };
+/* OR-ed into score_site: the caller wants the scores only — x_dev is scratch after the call.  The last block of the range then
+ * stops behind its hooked activation (its fc2 + residual, whose result nothing reads, is not run).  The reference runs the whole
+ * model and discards the logits (src/vit_pruning.py:180); the scores are the same bits either way. */
+#define SSP2_SCORE_ONLY 0x10
 
 /* score arithmetic: fp32 accumulators end to end, or the reference's CPU-autocast bf16 rounding points
  * (src/vit_pruning.py:151-157: per-(sample,neuron) norm -> bf16, batch sum -> bf16)                     */

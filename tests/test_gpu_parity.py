@@ -1120,3 +1120,25 @@ def test_zigzag_launch_order_does_not_change_a_bit(gpu, monkeypatch):
     for x, y, z in zip(a, b, c):
         assert torch.equal(x, y) and torch.equal(x, z)
     assert ca == cb == cc
+
+
+def test_scores_only_forward_stops_behind_the_last_hooked_activation_with_the_same_scores(gpu):
+    """SSP2_SCORE_ONLY (include/ssp2vit.h): stage 1 needs nothing behind the last block's hooked activation, so
+    VitEngine.forward_scores leaves that block's fc2 + residual out.  The scores are the same bits as those of the full
+    forward (what the reference runs, src/vit_pruning.py:180), both score sites, also as a side product of the forward that
+    goes on to the logits; x really is left one fc2 short."""
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_base_patch16_224_d3", classes=10, seed=3, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
+    eng = VitEngine(w, max_images=40)
+    g = torch.Generator().manual_seed(2)
+    px = torch.randn(40, 3, 224, 224, generator=g).to(gpu)
+    for site in ("pre_gelu", "post_gelu"):
+        short = eng.forward_scores(px, site, group=8)
+        x = eng.embed(px, group=8)
+        full = eng.layers(x, 40, 0, eng.depth, None, site, "fp32", None, 8)
+        assert torch.equal(short, full) and bool(torch.isfinite(full).all())
+        x2 = eng.embed(px, group=8)
+        eng.layers(x2, 40, 0, eng.depth, None, site, "fp32", None, 8, scores_only=True)
+        assert not torch.equal(x, x2)                    # the last fc2 did not run
+    assert eng.lib.ssp2_layers(eng.h, x.data_ptr(), 40, 0, eng.depth, None, 0x10, 0, 8, None, eng.score_ld) != 0   # the flag without a site
