@@ -166,11 +166,19 @@ def vit_b16_case():
     res = quiet(ref_vp.prune_vit_mlp_width, copy.deepcopy(model), n_to_prune_per_block=[1120] * 12, min_remaining=512,
                 collect_masks=True, precomputed_importance=[x.to(torch.float32) for x in imps])
     rec["mask.t1120"] = np.packbits(np.asarray(res["ffn_prune_masks"], dtype=np.uint8), axis=1)
+    # BASELINE configs[2] sweeps 25 / 37.5 / 50 % from ONE stage-1 pass and ONE search (main.py:152-157 convention): the
+    # planner's other two answers for this model are (K, t) = (4, 661) and (7, 1450); same scores, the reference's own mask step
+    for t in (661, 1450):
+        r2 = quiet(ref_vp.prune_vit_mlp_width, copy.deepcopy(model), n_to_prune_per_block=[t] * 12, min_remaining=512,
+                   collect_masks=True, precomputed_importance=[x.to(torch.float32) for x in imps])
+        rec[f"mask.t{t}"] = np.packbits(np.asarray(r2["ffn_prune_masks"], dtype=np.uint8), axis=1)
     rec["top1"] = np.float64(ref_vp.evaluate_top1(model, batches, device="cpu"))
     iface = ref_mc.Auto2SSPInterface(model, batches, device="cpu", importance_mode="copy", batch_limit=5)
     rec["att_imp"] = quiet(iface._compute_att_depth_importance).numpy()
     sel = [int(i) for i in torch.argsort(torch.from_numpy(rec["att_imp"]))[:5]]          # auto_2ssp.py:857, K = 5
     rec["s2_selected_k5"] = np.asarray(sorted(sel), dtype=np.int64)
+    for K in (4, 7):                                                                     # the sweep's other two depth targets
+        rec[f"s2_selected_k{K}"] = np.asarray(sorted(int(i) for i in torch.argsort(torch.from_numpy(rec["att_imp"]))[:K]), dtype=np.int64)
     o32 = ref_cpu.ffn_activation_importance(model, batches, chain="fp32")
     for i, t in enumerate(o32):
         rec[f"oracle_fp32.{i}"] = t.numpy()

@@ -143,6 +143,13 @@ def test_vit_b16_headline_geometry_pins_the_oracle():
     masks, _ = ref_cpu.width_prune_selection([t.to(torch.float32) for t in imps], [1120] * 12, min_remaining=512)
     assert np.array_equal(np.packbits(np.asarray(masks, dtype=np.uint8), axis=1), z["mask.t1120"])
     assert all(sum(m) == 1120 for m in masks)
+    # BASELINE configs[2]: the sweep's other two targets (planner: 25 % -> K = 4, t = 661; 50 % -> K = 7, t = 1450), the very
+    # same scores and the very same search — the reference's own mask step / argsort outputs for them
+    for t in (661, 1450):
+        mt, _ = ref_cpu.width_prune_selection([x.to(torch.float32) for x in imps], [t] * 12, min_remaining=512)
+        assert np.array_equal(np.packbits(np.asarray(mt, dtype=np.uint8), axis=1), z[f"mask.t{t}"]) and all(sum(m) == t for m in mt)
+    for K in (4, 7):
+        assert ref_cpu.select_blocks_torch_argsort(torch.from_numpy(z["att_imp"]), K) == z[f"s2_selected_k{K}"].tolist()
     # stage-2 selection rule on the reference's own impact vector (auto_2ssp.py:857, K = 5)
     assert ref_cpu.select_blocks_torch_argsort(torch.from_numpy(z["att_imp"]), 5) == z["s2_selected_k5"].tolist()
     assert z["att_imp"].shape == (12,) and float(z["top1"]) == 1.0 and sum(len(z[f"labels.{i}"]) for i in range(2)) == 64
