@@ -88,7 +88,7 @@ def run_one(args, target, run_id):
     mlp_imp = iface._compute_mlp_importance() if (args.stage in ("both", "s1") and args.s1_importance == "act") else None
     att_imp = iface._compute_att_depth_importance() if args.stage in ("both", "s2") else None
 
-    ffn_masks = None
+    ffn_masks = mask_parity = None
     if args.stage in ("both", "s1"):
         if args.stage == "both":
             n_prune = [plan.per_block_neurons_to_prune] * B
@@ -101,6 +101,7 @@ def run_one(args, target, run_id):
                                      collect_masks=True,
                                      precomputed_importance=[x.to(torch.float32) for x in mlp_imp] if mlp_imp is not None else None)
         ffn_masks = res["ffn_prune_masks"]
+        mask_parity = res.get("mask_parity")
     params_s1 = vp.count_total_params(model) if args.stage != "s2" else params_before
     t_s1 = time.time()
     latency_s1 = measure_latency(model, device, img_size=img)
@@ -175,6 +176,8 @@ def run_one(args, target, run_id):
     }
     if plan is not None:
         report["plan"] = dict(plan.__dict__)
+    if mask_parity is not None:          # per-block cut margin / tie band of the masks just cut (ssp2vit/mask_parity.py)
+        report["mask_parity"] = dict(mask_parity, score_chain=args.score_chain)
     saved = vp.save_report(report, str(out_root / "reports"), run_id=run_id)
     print("[SUMMARY]")
     print(json.dumps(report["metrics"], indent=2))

@@ -11,6 +11,7 @@ from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 import torch
 
 from . import dist as _dist
+from .mask_parity import mask_parity_report
 
 
 def iter_limited(dataloader: Iterable, limit: Optional[int], progress: bool, desc: str):
@@ -461,3 +462,25 @@ def impacts_from_counts(base: int, cand: Sequence[int], total: int) -> List[floa
     """impact_i = max(0, baseline - acc_i) with the reference's float arithmetic (mask_conjunction.py:329-348)."""
     baseline = float(base / max(1, total))
     return [max(0.0, baseline - float(c / max(1, total))) for c in cand]
+
+
+def select_for_targets(imps: Sequence[torch.Tensor], impact: torch.Tensor, plans: Sequence) -> List[dict]:
+    """The host half of a prune for one or several targets from ONE stage-1 pass and ONE search (BASELINE configs[2]:
+    25 / 37.5 / 50 % — the sweep convention of main.py:152-157): per plan the a7 mask step on the final score vectors
+    (reference src/vit_pruning.py:273-295: keep = sort(argsort(imp, descending)[:d_int - t]), 1 = prune), the a9 block
+    selection `torch.argsort(att_imp)[:K]` (auto_2ssp.py:857) and the cut-margin table of those masks.
+    Returns [{"target", "masks": [int16 [d_int]] * L, "blocks": sorted [int], "mask_parity": {...}}]."""
+    impact = torch.as_tensor(impact, dtype=torch.float32)
+    out = []
+    for p in plans:
+        t = int(p.per_block_neurons_to_prune)
+        masks = []
+        for imp in imps:
+            keep, _ = torch.sort(torch.argsort(imp, descending=True)[: imp.numel() - t])
+            m = torch.ones(imp.numel(), dtype=torch.int16)
+            m[keep] = 0
+            masks.append(m)
+        blocks = sorted(int(i) for i in torch.argsort(impact)[: int(p.blocks_to_prune)])
+        out.append({"target": float(p.target_sparsity), "masks": masks, "blocks": blocks,
+                    "mask_parity": mask_parity_report(imps, [t] * len(imps), min_remaining=0)})
+    return out

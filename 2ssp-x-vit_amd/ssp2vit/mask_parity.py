@@ -1,0 +1,53 @@
+"""Cut-margin / tie-band diagnostics of the mask step (SURVEY.md section 7 "hard parts" (iii); reference
+src/vit_pruning.py:273-295).  Host arithmetic only."""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+# The mask step (reference :273-295) is a discrete function of the scores: `argsort(imp, descending)[:keep]`.  Two runs
+# whose scores differ by a relative error of at most e give the SAME mask whenever the gap between the weakest kept and
+# the strongest pruned neuron exceeds 2e (no pair can then change sides), and may differ otherwise; with the
+# reference's own bf16 score chain exact ties across the cut are decided by an unstable sort (:286) and nothing can be
+# promised at all.  MASK_PARITY_EPS is that gap threshold: twice the 5e-4 bound on the engine's fp32-chain score error
+# against the CPU restatement (measured on MI355X: <= 4.6e-4 ViT-Ti/16, <= 3.0e-4 ViT-B/16).
+MASK_PARITY_EPS = float(os.environ.get("SSP2_MASK_PARITY_EPS", "1e-3"))
+
+
+def mask_parity_report(scores: Sequence[torch.Tensor], n_prune_per_block: Sequence[int], min_remaining: int = 256,
+                       eps: Optional[float] = None) -> Dict[str, Any]:
+    """Per block, for the cut the mask step is about to make on `scores`:
+      cut_margin        (weakest kept - strongest pruned) / weakest kept, relative
+      tie_band          neurons within the +-eps band of the cut: kept ones at most (1+eps) x the strongest pruned score
+                        plus pruned ones at least (1-eps) x the weakest kept score — the only neurons whose side a score
+                        error below eps/2 could change (0 <=> cut_margin > eps)
+      exact_ties        neurons whose score EQUALS a score on the other side of the cut (bf16 chains: sort-order lottery)
+      guaranteed        tie_band == 0: the mask equals the one a CPU run of the reference algorithm makes from its own
+                        fp32 scores, as long as the two score vectors agree to eps/2
+    plus `eps`, `blocks_guaranteed`, `min_margin`.  Pure host arithmetic on the final [L][d_int] score vectors."""
+    eps = MASK_PARITY_EPS if eps is None else float(eps)
+    blocks: List[Dict[str, Any]] = []
+    for b, imp in enumerate(scores):
+        imp = imp.detach().to("cpu", torch.float64).view(-1)
+        width = imp.numel()
+        drop = int(n_prune_per_block[b])
+        if width - drop < min_remaining:
+            drop = max(0, width - min_remaining)
+        if drop <= 0 or drop >= width:
+            blocks.append({"block": b, "pruned": max(0, min(drop, width)), "cut_margin": None, "tie_band": 0,
+                           "exact_ties": 0, "guaranteed": True})
+            continue
+        s = torch.sort(imp, descending=True).values
+        kept_min, pruned_max = float(s[width - drop - 1]), float(s[width - drop])
+        margin = (kept_min - pruned_max) / kept_min if kept_min > 0 else 0.0
+        kept, pruned = s[: width - drop], s[width - drop:]
+        band = int((kept <= pruned_max * (1.0 + eps)).sum()) + int((pruned >= kept_min * (1.0 - eps)).sum())
+        ties = (int((kept == pruned_max).sum()) + int((pruned == kept_min).sum())) if kept_min == pruned_max else 0
+        blocks.append({"block": b, "pruned": drop, "cut_margin": margin, "tie_band": band, "exact_ties": ties,
+                       "guaranteed": band == 0})
+    margins = [x["cut_margin"] for x in blocks if x["cut_margin"] is not None]
+    return {"eps": eps, "blocks": blocks, "blocks_guaranteed": sum(1 for x in blocks if x["guaranteed"]),
+            "blocks_total": len(blocks), "min_margin": min(margins) if margins else None,
+            "rule": "mask == CPU-reference mask from fp32 scores wherever tie_band == 0 (cut_margin > eps = 2 x score error bound)"}

@@ -22,11 +22,13 @@ import torch.nn as nn
 from . import core as _core
 from . import dist as _dist
 from . import weights as _weights
+from .mask_parity import MASK_PARITY_EPS, mask_parity_report
 from .planner import ModelStats, TwoSSPPlan, plan_from_stats
 
 __all__ = [
     "prune_vit_mlp_width", "evaluate_top1", "prune_vit_attention_blocks", "plan_2ssp_allocation",
     "count_total_params", "count_block_params", "compute_actual_sparsity", "save_report", "TwoSSPPlan",
+    "mask_parity_report", "MASK_PARITY_EPS",
 ]
 
 
@@ -222,6 +224,8 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
 
     all_idx: List[List[int]] = []
     all_masks: List[List[int]] = []
+    used_scores: List[torch.Tensor] = []
+    used_drop: List[int] = []
     for b, (fc1, fc2) in enumerate(pairs):
         w1, b1, w2 = fc1.weight, fc1.bias, fc2.weight
         width = w1.size(0)
@@ -238,6 +242,7 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
         drop = int(n_to_prune_per_block[b]) if n_to_prune_per_block is not None else int(width * sparsity)
         if width - drop < min_remaining:
             drop = max(0, width - min_remaining)
+        used_scores.append(imp.detach()); used_drop.append(drop)
         if drop <= 0:
             continue
         keep, _ = torch.sort(torch.argsort(imp, descending=True)[: width - drop])
@@ -254,7 +259,9 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
         fc2.weight = nn.Parameter(w2[:, keep].clone())
         fc2.in_features = int(keep.numel())
     if collect_masks:
-        return {"model": vit_model, "ffn_pruned_indices": all_idx, "ffn_prune_masks": all_masks}
+        # the reference's three keys (:313-318) + this build's cut-margin table for the very scores the masks were cut from
+        return {"model": vit_model, "ffn_pruned_indices": all_idx, "ffn_prune_masks": all_masks,
+                "mask_parity": mask_parity_report(used_scores, used_drop, min_remaining=0)}
     return vit_model
 
 
@@ -419,6 +426,14 @@ def save_report(report: Dict[str, Any], out_dir: str, run_id: Optional[str] = No
                f"- Per-block neurons to prune (Stage-1): {g('per_block_neurons_to_prune')}",
                f"- Estimated total removed params: {g('estimated_total_removed_params')}",
                f"- Estimation error (params): {g('est_error_params')}", ""]
+    mp_ = report.get("mask_parity")
+    if mp_:
+        md += ["## Mask parity (cut margins of the stage-1 masks)",
+               f"- eps (twice the score error bound): {mp_.get('eps')}",
+               f"- blocks whose mask is guaranteed equal to a CPU run's: {mp_.get('blocks_guaranteed')} of {mp_.get('blocks_total')}",
+               f"- smallest relative cut margin: {mp_.get('min_margin')}"]
+        md += [f"- block {b['block']}: margin {b['cut_margin']}, tie band {b['tie_band']}, exact ties {b['exact_ties']}"
+               for b in mp_.get("blocks", []) if not b.get("guaranteed", True)] + [""]
     if "artifacts" in report:
         md += ["## Artifacts"] + [f"- {k}: {v}" for k, v in report["artifacts"].items()] + [""]
     with open(mp, "w", encoding="utf-8") as f:

@@ -737,6 +737,33 @@ def test_vit_b16_scores_masks_and_depth_importance_vs_reference_golden(gpu):
             asserted += 1
     print(f"[b16-parity] masks identical in {asserted} blocks where the cut margin guarantees it; {differing} differing mask bits in all")
     assert differing <= 8, (asserted, differing)
+    # BASELINE configs[2] on the same fixture: the sweep's three targets from this ONE stage-1 pass, through the product's
+    # own host half (core.select_for_targets) and its cut-margin report.  Rule asserted (the PRODUCT's rule, ssp2vit/mask_parity.py):
+    # every block the report calls `guaranteed` (no neuron inside the +-eps band of the cut, eps = 1e-3) has the oracle-score
+    # mask, at every target; overall <= 8 differing bits per target as above.
+    from ssp2vit.mask_parity import MASK_PARITY_EPS
+    from ssp2vit.planner import plan_from_stats, stats_from_shapes
+    plans = [plan_from_stats(stats_from_shapes(768, 12, 3072, 1000, 197, 16), t, 512) for t in (0.25, 0.375, 0.5)]
+    assert [(p.blocks_to_prune, p.per_block_neurons_to_prune) for p in plans] == [(4, 661), (5, 1120), (7, 1450)]
+    sweep = core.select_for_targets(got_f, torch.zeros(12), plans)
+    for o, p in zip(sweep, plans):
+        t = p.per_block_neurons_to_prune
+        om, _ = ref_cpu.width_prune_selection(ref_f, [t] * 12, min_remaining=512)
+        mp = o["mask_parity"]
+        assert mp["eps"] == MASK_PARITY_EPS == 1e-3
+        bits = 0
+        for l in range(12):
+            d = int((o["masks"][l].numpy() != np.asarray(om[l], dtype=np.int16)).sum())
+            bits += d
+            b = mp["blocks"][l]
+            vs_ref = int((o["masks"][l].numpy().astype(np.uint8) != np.unpackbits(z[f"mask.t{t}"], axis=1)[l, :3072]).sum())
+            print(f"[b16-sweep] t={t} block {l:2d}: cut margin {b['cut_margin']:.2e}, tie band {b['tie_band']}, guaranteed {b['guaranteed']} | "
+                  f"bits differing from the oracle-score mask {d}, from the reference's bf16-score mask {vs_ref}")
+            if b["guaranteed"]:
+                assert d == 0, (t, l, b)
+            assert int(o["masks"][l].sum()) == t
+        print(f"[b16-sweep] t={t}: {mp['blocks_guaranteed']} of 12 blocks guaranteed, {bits} differing bits in all")
+        assert bits <= 8, (t, bits)
     # stage 2 on the reference's teacher labels
     base, cand, total = core.depth_search_counts(eng, batches, 12, batch_limit=5, chunk_images=64)
     assert total == 64 and abs(base / 64 - float(z["top1"])) <= 1 / 64 + 1e-9
@@ -754,6 +781,18 @@ def test_vit_b16_scores_masks_and_depth_importance_vs_reference_golden(gpu):
         assert sel == ref_sel
     else:
         assert len(set(sel) & set(ref_sel)) >= 4
+    # the sweep's other two depth targets (K = 4, 7) from the same impact vector, against the reference's own selections:
+    # identical when the reference's gap at that cut exceeds the 3-image tolerance, else at most one block apart
+    for K in (4, 7):
+        sel_k = core.select_for_targets(got_f, att, [plans[0 if K == 4 else 2]])[0]["blocks"]
+        ref_k = z[f"s2_selected_k{K}"].tolist()
+        gap_k = float(srt[K] - srt[K - 1]) * 64
+        print(f"[b16-sweep] K={K} selection: engine {sel_k} reference {ref_k}; reference gap at the cut {gap_k:.0f} image(s)")
+        assert sel_k == ref_cpu.select_blocks_torch_argsort(att, K)
+        if gap_k > 3:
+            assert sel_k == ref_k
+        else:
+            assert len(set(sel_k) & set(ref_k)) >= K - 1
     eng.close()
 
 
@@ -888,6 +927,146 @@ def test_vit_h14_one_rank_shard_of_config4_properties(gpu):
     for c in (0, 17, 31):
         assert core.top1_counts(eng, evalb, attn_skip=[c], chunk_images=64) == (cand[c], 64)
     eng.close()
+
+
+def test_config2_full_size_three_target_sweep_on_one_rank(gpu):
+    """BASELINE configs[2] at N = 1 and at its full size: ViT-B/16, 2048 calibration + 2560 evaluation images (batches of
+    64, teacher labels), ONE stage-1 pass and ONE search, then the three targets 0.25 / 0.375 / 0.5 (planner: K = 4 / 5 / 7,
+    t = 661 / 1120 / 1450) through core.select_for_targets and VitEngine.apply_into — what `bench.py --config 2` times.
+    The oracle would need ~10 minutes for this, so size-independent properties (reference: main.py:152-157 sweep
+    convention, src/vit_pruning.py:273-295 mask step, auto_2ssp.py:857 selection):
+      * packing invariance: stage-1 scores of 512-image launches == 64-image launches, bit for bit; run-to-run determinism
+      * the search: layer-major in 320-image chunks == candidate-major in 64-image chunks (integers), baseline 2560 / 2560
+      * per target: every mask prunes exactly t neurons; masks are NESTED across targets (the 661 pruned at 25 % are
+        among the 1120 at 37.5 %, those among the 1450 at 50 % — one ranking, three cuts); blocks == torch.argsort(impact)[:K]
+        and nested as well; the cut-margin report is present for every block
+      * apply: the pruned twin of each target has the planned widths and its top-1 on 128 images equals that of an engine
+        built from host-sliced weights of the same masks (integers)"""
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.planner import plan_from_stats, stats_from_shapes
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_base_patch16_224", classes=1000, seed=0, std=0.02, eps=1e-6, spread=4.0)
+    eng = VitEngine(w, max_images=12 * 320)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    calib = [{"pixel_values": torch.randn(64, 3, 224, 224, generator=g, device="cuda")} for _ in range(32)]
+    evalb = []
+    for _ in range(40):
+        px = torch.randn(64, 3, 224, 224, generator=g, device="cuda")
+        x = eng.embed(px); eng.layers(x, 64)
+        evalb.append({"pixel_values": px, "labels": eng.head(x, 64, want_pred=True)[1].long()})
+    d_ints = [3072] * 12
+    imps = core.stage1_scores(eng, calib, d_ints, "pre_gelu", chunk_images=512)
+    again = core.stage1_scores(eng, calib, d_ints, "pre_gelu", chunk_images=512)
+    small = core.stage1_scores(eng, calib, d_ints, "pre_gelu", chunk_images=64)
+    for a, b, c in zip(imps, again, small):
+        assert torch.equal(a, b) and torch.equal(a, c) and bool(torch.isfinite(a).all()) and float(a.min()) > 0
+    base, cand, total = core.depth_search_counts(eng, evalb, 12, batch_limit=None, chunk_images=320, batch_candidates=True)
+    assert (base, total) == (2560, 2560) and len(cand) == 12 and all(0 <= c <= 2560 for c in cand)
+    assert (base, cand, total) == core.depth_search_counts(eng, evalb, 12, batch_limit=None, chunk_images=64, batch_candidates=False)
+    impact = torch.tensor(core.impacts_from_counts(base, cand, total), dtype=torch.float32)
+    plans = [plan_from_stats(stats_from_shapes(768, 12, 3072, 1000, 197, 16), t, 512) for t in (0.25, 0.375, 0.5)]
+    assert [(p.blocks_to_prune, p.per_block_neurons_to_prune) for p in plans] == [(4, 661), (5, 1120), (7, 1450)]
+    sweep = core.select_for_targets(imps, impact, plans)
+    print()
+    for o, p in zip(sweep, plans):
+        t, K = p.per_block_neurons_to_prune, p.blocks_to_prune
+        assert all(int(m.sum()) == t and m.numel() == 3072 for m in o["masks"])
+        assert o["blocks"] == sorted(int(i) for i in torch.argsort(impact)[:K])
+        mp = o["mask_parity"]
+        assert mp["blocks_total"] == 12 and all(b["cut_margin"] is not None and b["cut_margin"] >= 0 for b in mp["blocks"])
+        print(f"[config2] target {p.target_sparsity}: K={K} blocks {o['blocks']}, t={t}, masks guaranteed in {mp['blocks_guaranteed']}/12 "
+              f"blocks, min cut margin {mp['min_margin']:.2e}")
+    for lo, hi in ((0, 1), (1, 2)):
+        for l in range(12):
+            assert bool(((sweep[lo]["masks"][l] == 1) <= (sweep[hi]["masks"][l] == 1)).all()), "masks not nested across targets"
+        assert set(sweep[lo]["blocks"]) <= set(sweep[hi]["blocks"])
+    test_px = [b for b in evalb[:2]]
+    for o, p in zip(sweep, plans):
+        twin = eng.pruned_twin([3072 - p.per_block_neurons_to_prune] * 12, max_images=128)
+        eng.apply_into(twin, o["masks"], o["blocks"])
+        assert twin.d_int == [3072 - p.per_block_neurons_to_prune] * 12 and [i for i, a in enumerate(twin.absent) if a] == o["blocks"]
+        got = core.top1_counts(twin, test_px, chunk_images=128)
+        ws = dict(w)
+        for l in range(12):
+            keep = torch.nonzero(o["masks"][l] == 0).view(-1)
+            ws[f"fc1_w.{l}"] = w[f"fc1_w.{l}"][keep].clone(); ws[f"fc1_b.{l}"] = w[f"fc1_b.{l}"][keep].clone()
+            ws[f"fc2_w.{l}"] = w[f"fc2_w.{l}"][:, keep].clone()
+        ref_eng = VitEngine(ws, max_images=128)
+        assert got == core.top1_counts(ref_eng, test_px, attn_skip=o["blocks"], chunk_images=128), p.target_sparsity
+        ref_eng.close(); twin.close()
+    eng.close()
+
+
+def test_config4_fp8_leg_full_depth_vit_h14_vs_the_bf16_engine(gpu):
+    """BASELINE configs[4], fp8 leg, FULL depth: ViT-H/14 (32 blocks, d = 1280, d_int = 5120, 257 tokens), one rank's shard of
+    512 calibration images, 2SSP @ 50 % (planner: K = 15, t = 2656).  The reference has no fp8 arithmetic, so the yardstick
+    is this build's bf16 engine on the same inputs (parity unpinned by nature).  Thresholds, written before the first
+    run on hardware:
+      * stage-1 scores (fp32 chain): finite, positive; per-block mean relative error vs bf16 <= 6 %
+      * masks at t = 2656: >= 93 % of the 5120 bits equal in EVERY block, >= 97 % over the whole model
+      * dense fp8 engine on the bf16 engine's own labels (128 images): >= 50 % top-1 agreement (random-init logits are
+        nearly flat; printed)
+      * depth importance on 128 images, each engine on the bf16 teacher labels: Pearson correlation of the two impact
+        vectors >= 0.8 and the K = 15 selections share >= 10 blocks (chance: 7)
+      * fp8 packing invariance: 512-image launch == 64-image launches, bit for bit"""
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.planner import plan_from_stats, stats_from_shapes
+    from ssp2vit.weights import synthetic_weights
+    L = 32
+    w = synthetic_weights("vit_huge_patch14_224", classes=1000, seed=0, std=0.02, eps=1e-6, spread=4.0)
+    plan = plan_from_stats(stats_from_shapes(1280, L, 5120, 1000, 257, 14), 0.5, min_remaining=512)
+    assert (plan.blocks_to_prune, plan.per_block_neurons_to_prune) == (15, 2656)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    calib = [{"pixel_values": torch.randn(64, 3, 224, 224, generator=g, device="cuda")} for _ in range(8)]
+    eval_px = [torch.randn(64, 3, 224, 224, generator=g, device="cuda") for _ in range(2)]
+    d_ints = [5120] * L
+    res = {}
+    for prec in ("bf16", "fp8"):
+        eng = VitEngine(w, max_images=512, precision=prec)
+        imps = core.stage1_scores(eng, calib, d_ints, "pre_gelu", chunk_images=512)
+        if prec == "fp8":
+            small = core.stage1_scores(eng, calib, d_ints, "pre_gelu", chunk_images=64)
+            assert all(torch.equal(a, b) for a, b in zip(imps, small)), "fp8 stage 1 depends on the packing"
+        if prec == "bf16":
+            evalb = []
+            for px in eval_px:
+                x = eng.embed(px); eng.layers(x, 64)
+                evalb.append({"pixel_values": px, "labels": eng.head(x, 64, want_pred=True)[1].long()})
+        base, cand, total = core.depth_search_counts(eng, evalb, L, batch_limit=None, chunk_images=128, batch_candidates=False)
+        res[prec] = (imps, base, cand, total)
+        eng.close()
+        torch.cuda.empty_cache()
+    (ib, bb, cb, tb), (i8, b8, c8, t8) = res["bf16"], res["fp8"]
+    assert tb == t8 == 128 and bb == 128
+    print()
+    same_bits = 0
+    for l in range(L):
+        assert bool(torch.isfinite(i8[l]).all()) and float(i8[l].min()) > 0
+        rel = float(((i8[l] - ib[l]).abs() / ib[l]).mean())
+        mb = _mask_of(ib[l], 2656)
+        m8 = _mask_of(i8[l], 2656)
+        agree = float((mb == m8).float().mean())
+        same_bits += int((mb == m8).sum())
+        print(f"[h14-fp8] block {l:2d}: score mean rel err {100 * rel:.2f} %, mask agreement at t=2656 {100 * agree:.2f} %")
+        assert rel <= 0.06, (l, rel)
+        assert agree >= 0.93, (l, agree)
+    assert same_bits / (L * 5120) >= 0.97, same_bits / (L * 5120)
+    print(f"[h14-fp8] dense fp8 top-1 on the bf16 labels: {b8}/128; whole-model mask agreement {100 * same_bits / (L * 5120):.2f} %")
+    assert b8 >= 64
+    ab = torch.tensor(core.impacts_from_counts(bb, cb, tb)); a8 = torch.tensor(core.impacts_from_counts(b8, c8, t8))
+    corr = float(torch.corrcoef(torch.stack([ab, a8]))[0, 1])
+    sb = set(int(i) for i in torch.argsort(ab)[:15]); s8 = set(int(i) for i in torch.argsort(a8)[:15])
+    print(f"[h14-fp8] impacts (images of 128): bf16 {[round(float(v) * 128) for v in ab]}\n[h14-fp8]                           fp8  "
+          f"{[round(float(v) * 128) for v in a8]}\n[h14-fp8] correlation {corr:.3f}, K=15 overlap {len(sb & s8)}/15")
+    assert corr >= 0.8 and len(sb & s8) >= 10
+
+
+def _mask_of(imp, t):
+    keep, _ = torch.sort(torch.argsort(imp, descending=True)[: imp.numel() - t])
+    m = torch.ones(imp.numel(), dtype=torch.int16); m[keep] = 0
+    return m
 
 
 def test_torch_ops_give_the_same_bits_as_the_ctypes_path(gpu):

@@ -61,6 +61,8 @@ def test_width_prune_mask_step_matches_reference_golden(layout):
     assert np.array_equal(np.asarray(res["ffn_prune_masks"], dtype=np.int16), z["mask.t40"])
     assert np.array_equal(np.asarray(res["ffn_pruned_indices"]), z["pruned_idx.t40"])
     assert res["model"] is model
+    mp = res["mask_parity"]                              # this build's fourth key: cut margins of the masks just made
+    assert mp["blocks_total"] == 4 and [b["pruned"] for b in mp["blocks"]] == [40] * 4 and mp["eps"] == vp.MASK_PARITY_EPS
     # weight surgery equals the reference's: the pruned model's top-1 (oracle forward) equals the stored value
     assert ref_cpu.evaluate_top1(model, batches) == float(z["top1_after.t40"])
     pairs = vp._gather_mlp_pairs(model)
@@ -70,6 +72,70 @@ def test_width_prune_mask_step_matches_reference_golden(layout):
     res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[100] * 4, min_remaining=64, collect_masks=True,
                                  precomputed_importance=imps)
     assert np.array_equal(np.asarray(res["ffn_prune_masks"], dtype=np.int16), z["mask.t100_clamped"])
+
+
+def test_mask_parity_report_theorem_and_fields():
+    """ssp2vit.mask_parity: a block is `guaranteed` iff no neuron lies in the +-eps band of the cut, and then NO score
+    perturbation of relative size < eps / 2 can change the mask (checked by perturbing adversarially and at random);
+    exact ties across the cut are counted; the clamp by min_remaining follows the mask step's."""
+    from oracle import ref_cpu
+    from ssp2vit.mask_parity import MASK_PARITY_EPS, mask_parity_report
+    g = torch.Generator().manual_seed(3)
+    scores = [torch.rand(512, generator=g) + 0.05 for _ in range(6)]
+    srt = torch.sort(scores[1], descending=True)
+    scores[1][srt.indices[300]] = srt.values[299] * (1 - 2e-4)          # a pair 2e-4 apart straddling the cut at 212 pruned
+    scores[2] = scores[2].to(torch.bfloat16).to(torch.float32)
+    s2 = torch.sort(scores[2], descending=True)
+    scores[2][s2.indices[300]] = s2.values[299]                          # an exact tie across the cut
+    rep = mask_parity_report(scores, [212] * 6, min_remaining=16)
+    assert rep["eps"] == MASK_PARITY_EPS == 1e-3 and rep["blocks_total"] == 6
+    b1, b2 = rep["blocks"][1], rep["blocks"][2]
+    assert not b1["guaranteed"] and b1["tie_band"] >= 2 and abs(b1["cut_margin"] - 2e-4) < 1e-6 and b1["exact_ties"] == 0
+    assert not b2["guaranteed"] and b2["exact_ties"] >= 2 and b2["cut_margin"] == 0.0
+    assert rep["min_margin"] == 0.0 and rep["blocks_guaranteed"] == sum(b["guaranteed"] for b in rep["blocks"])
+    base, _ = ref_cpu.width_prune_selection(scores, [212] * 6, min_remaining=16)
+    for trial in range(4):
+        e = 0.49 * rep["eps"]
+        if trial == 0:       # adversarial: everything kept goes down, everything pruned goes up
+            pert = [s * torch.where(torch.tensor(m, dtype=torch.bool), 1 + e, 1 - e) for s, m in zip(scores, base)]
+        else:
+            pert = [s * (1 + e * (2 * torch.rand(512, generator=g) - 1)) for s in scores]
+        got, _ = ref_cpu.width_prune_selection(pert, [212] * 6, min_remaining=16)
+        for b in rep["blocks"]:
+            if b["guaranteed"]:
+                assert got[b["block"]] == base[b["block"]], (trial, b)
+    assert ref_cpu.width_prune_selection([s * torch.where(torch.tensor(m, dtype=torch.bool), 1 + 5e-4, 1 - 5e-4)
+                                          for s, m in zip(scores, base)], [212] * 6, min_remaining=16)[0][1] != base[1]
+    clamp = mask_parity_report(scores[:1], [600], min_remaining=500)
+    assert clamp["blocks"][0]["pruned"] == 12
+    assert mask_parity_report(scores[:1], [0])["blocks"][0] == {"block": 0, "pruned": 0, "cut_margin": None, "tie_band": 0,
+                                                                "exact_ties": 0, "guaranteed": True}
+
+
+def test_select_for_targets_on_the_b16_golden_scores_gives_the_reference_masks_and_selections():
+    """BASELINE configs[2] host half (core.select_for_targets): from the REAL reference's ViT-B/16 scores and impact
+    vector (tests/golden/vit_b16_2x32.npz) the three targets' masks and block selections equal the reference's own
+    (t = 661 / 1120 / 1450, K = 4 / 5 / 7), and the cut-margin table says which blocks of that bf16 score set are
+    decided by ties (the reference's unstable argsort, src/vit_pruning.py:286)."""
+    from ssp2vit import core
+    from ssp2vit.planner import plan_from_stats, stats_from_shapes
+    z = dict(np.load(os.path.join(GOLDEN, "vit_b16_2x32.npz")))
+    imps = [bf16_from_bits(z[f"s1_imp_bf16bits.{l}"]).to(torch.float32) for l in range(12)]
+    st = stats_from_shapes(768, 12, 3072, 1000, 197, 16)
+    plans = [plan_from_stats(st, t, 512) for t in (0.25, 0.375, 0.5)]
+    assert [(p.blocks_to_prune, p.per_block_neurons_to_prune) for p in plans] == [(4, 661), (5, 1120), (7, 1450)]
+    out = core.select_for_targets(imps, torch.from_numpy(z["att_imp"]), plans)
+    for o, p in zip(out, plans):
+        t, K = p.per_block_neurons_to_prune, p.blocks_to_prune
+        assert o["blocks"] == z[f"s2_selected_k{K}"].tolist()
+        ref = np.unpackbits(z[f"mask.t{t}"], axis=1)[:, :3072]
+        assert all(int(m.sum()) == t for m in o["masks"])
+        # same torch.argsort on the same floats: equal masks, ties included (same build of torch made the fixture)
+        assert np.array_equal(np.stack([m.numpy().astype(np.uint8) for m in o["masks"]]), ref)
+        mp = o["mask_parity"]
+        assert mp["blocks_total"] == 12 and len(mp["blocks"]) == 12 and all(b["pruned"] == t for b in mp["blocks"])
+    # bf16 scores: few distinct values per block, so cuts land inside runs of equal scores
+    assert sum(b["exact_ties"] > 0 for b in out[1]["mask_parity"]["blocks"]) >= 1
 
 
 def test_width_prune_argument_errors_like_reference():
