@@ -60,18 +60,30 @@ def run_one(args, target, run_id):
     device = "cuda"
     if not torch.cuda.is_available():
         raise SystemExit("auto_2ssp needs an MI355X: the product path has no CPU fallback")
-    name = args.model if args.model in VIT_CONFIGS else "vit_base_patch16_224"
-    img = VIT_CONFIGS[name][0]
-    model = EngineViT(synthetic_weights(name, classes=args.num_classes, seed=args.seed, std=0.02, spread=4.0))
+    pg = _process_group()
+    rank0 = pg is None or torch.distributed.get_rank() == 0
+    if args.weights:
+        # a LOCAL checkpoint (reference :636-667 loads its model with from_pretrained / timm.create_model; the network
+        # fetches stay out): .safetensors / .pth state dict or an HF save_pretrained directory, any of the three key layouts
+        from ssp2vit.weights import load_checkpoint
+        flat = load_checkpoint(args.weights, heads=args.heads)
+        name = f"{os.path.basename(os.path.normpath(args.weights))} ({flat['layout']} layout, dim {flat['dim']}, depth {flat['depth']})"
+        img = int(flat["img"])
+    else:
+        name = args.model if args.model in VIT_CONFIGS else "vit_base_patch16_224"
+        img = VIT_CONFIGS[name][0]
+        flat = synthetic_weights(name, classes=args.num_classes, seed=args.seed, std=0.02, spread=4.0)
+    model = EngineViT(flat)
     test_loader, cal_loader = synthetic_loaders(model, img, args.batch_size, args.synthetic_calib, max(args.eval_batches, 1),
                                                 args.seed + 1, device)
-    print(f"[INFO] Using device: {device}; model={name}; synthetic calib={len(cal_loader) * args.batch_size} "
-          f"eval={len(test_loader) * args.batch_size} images")
+    if rank0:
+        print(f"[INFO] Using device: {device}; model={name}; synthetic calib={len(cal_loader) * args.batch_size} "
+              f"eval={len(test_loader) * args.batch_size} images; ranks={1 if pg is None else torch.distributed.get_world_size()}")
 
     params_before = vp.count_total_params(model)
     latency_baseline = measure_latency(model, device, img_size=img)
     maxb = args.baseline_eval_batches if args.baseline_eval_batches is not None else args.eval_batches
-    acc_baseline = vp.evaluate_top1(model, test_loader, device, max_batches=maxb) if (maxb is None or maxb > 0) else None
+    acc_baseline = vp.evaluate_top1(model, test_loader, device, max_batches=maxb, process_group=pg) if (maxb is None or maxb > 0) else None
     print(f"[STEP] Baseline computed: params={params_before}, latency_ms={round(latency_baseline * 1000, 2)}, acc={acc_baseline}")
 
     plan = None
@@ -84,7 +96,7 @@ def run_one(args, target, run_id):
     t_prune0 = time.time()
     imp_mode = "heuristic" if args.stage == "s1" else args.depth_importance
     iface = Auto2SSPInterface(model, cal_loader, device=device, importance_mode=imp_mode, batch_limit=args.eval_batches,
-                              min_remaining=args.min_remaining, score_chain=args.score_chain)
+                              min_remaining=args.min_remaining, score_chain=args.score_chain, process_group=pg)
     mlp_imp = iface._compute_mlp_importance() if (args.stage in ("both", "s1") and args.s1_importance == "act") else None
     att_imp = iface._compute_att_depth_importance() if args.stage in ("both", "s2") else None
 
@@ -105,7 +117,7 @@ def run_one(args, target, run_id):
     params_s1 = vp.count_total_params(model) if args.stage != "s2" else params_before
     t_s1 = time.time()
     latency_s1 = measure_latency(model, device, img_size=img)
-    acc_s1 = vp.evaluate_top1(model, test_loader, device, max_batches=args.eval_batches)
+    acc_s1 = vp.evaluate_top1(model, test_loader, device, max_batches=args.eval_batches, process_group=pg)
     print(f"[STAGE-1 DONE] params={params_s1}, latency_ms={round(latency_s1 * 1000, 2)}, acc={acc_s1}")
 
     pruned_indices = []
@@ -122,14 +134,17 @@ def run_one(args, target, run_id):
         sel = [int(i) for i in torch.argsort(att_imp)[:k]]                    # reference :857
         res = vp.prune_vit_attention_blocks(model, sparsity=frac, dataloader=test_loader, device=device,
                                             batch_limit=args.eval_batches, importance_mode=args.depth_importance,
-                                            show_progress=False, num_to_prune=k, selected_indices=sel)
+                                            show_progress=False, num_to_prune=k, selected_indices=sel, process_group=pg)
         pruned_indices = res["pruned_indices"]
     t_prune1 = time.time()
     params_s2 = vp.count_total_params(model)
     latency_s2 = measure_latency(model, device, img_size=img)
-    acc_s2 = vp.evaluate_top1(model, test_loader, device, max_batches=args.eval_batches)
+    acc_s2 = vp.evaluate_top1(model, test_loader, device, max_batches=args.eval_batches, process_group=pg)
     print(f"[STAGE-2 DONE] params={params_s2}, latency_ms={round(latency_s2 * 1000, 2)}, acc={acc_s2}, pruned_blocks={pruned_indices}")
 
+    if not rank0:                      # every rank holds the same scores, masks and selection; rank 0 writes the artefacts
+        vp.release_engines()
+        return None
     s1 = vp.compute_actual_sparsity(params_before, params_s1)
     s2 = vp.compute_actual_sparsity(params_s1, params_s2)
     st = vp.compute_actual_sparsity(params_before, params_s2)
@@ -155,7 +170,8 @@ def run_one(args, target, run_id):
         "config": {"model": name, "target_sparsity": target, "stage": args.stage, "s1_sparsity": args.s1_sparsity,
                    "s2_sparsity": args.s2_sparsity, "freeze_backbone": False, "replace_classifier": False, "use_adapter": False,
                    "adapter_reduction": None, "eval_batches": args.eval_batches, "min_remaining": args.min_remaining,
-                   "cifar_load": False, "dataset": "synthetic"},
+                   "cifar_load": False, "dataset": "synthetic", "weights": args.weights,
+                   "gpus": 1 if pg is None else torch.distributed.get_world_size()},
         "metrics": {
             "params_before_stage1": params_before, "params_after_stage1": params_s1, "params_after_stage2": params_s2,
             "params_before_stage1_millions": round(params_before / 1e6, 2), "params_after_stage1_millions": round(params_s1 / 1e6, 2),
@@ -186,6 +202,32 @@ def run_one(args, target, run_id):
     return report
 
 
+def _process_group():
+    return torch.distributed.group.WORLD if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
+
+
+def launcher_plan(argv, environ):
+    """`--gpus N` (N > 1) without a torch.distributed environment: the N-rank job to START — one process per GPU over RCCL,
+    the calibration / evaluation batches dealt round-robin (ssp2vit/dist.py) — or None when this process is a rank itself."""
+    import socket
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "RANK" in environ or "WORLD_SIZE" in environ:
+        return None
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return {"cmd": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                    "--master-port", port, str(Path(__file__).resolve()), *argv], "env": env, "n": n}
+
+
 def build_argparser():
     p = argparse.ArgumentParser(description="Auto 2SSP for ViT with single TARGET sparsity (MI355X-native engine).")
     p.add_argument("--model", type=str, default="vit_base_patch16_224", help=f"architecture: one of {sorted(VIT_CONFIGS)}")
@@ -208,6 +250,11 @@ def build_argparser():
     p.add_argument("--fw-export-prefix", type=str, default=None)
     p.add_argument("--output-dir", type=str, default=str(HERE / "runs"), help="reports/ and artifacts/ are created below it")
     # synthetic stand-ins for the network-loaded model/data of the reference
+    p.add_argument("--weights", type=str, default=None,
+                   help="LOCAL checkpoint instead of random init: .safetensors / .pth state dict or an HF save_pretrained directory "
+                        "(timm, transformers<5 or transformers>=5 key layout; width-pruned checkpoints load as they are)")
+    p.add_argument("--heads", type=int, default=None, help="attention heads, when the checkpoint carries no config.json")
+    p.add_argument("--gpus", type=int, default=1, help="N > 1: one process per GPU over RCCL, batches dealt round-robin (starts the ranks itself)")
     p.add_argument("--num-classes", type=int, default=1000)
     p.add_argument("--batch-size", type=int, default=64)
     p.add_argument("--synthetic-calib", type=int, default=512)
@@ -228,6 +275,10 @@ def build_argparser():
 
 def main(argv=None):
     args = build_argparser().parse_args(argv)
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))   # RCCL
     rate = args.sparsity_rate if args.sparsity_rate is not None else args.target
     targets = [0.25, 0.375, 0.5] if rate == -2 else [rate]
     if args.stage == "both" and any(t is None for t in targets):
@@ -237,4 +288,10 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
+    _plan = launcher_plan(sys.argv[1:], os.environ)
+    if _plan is not None:                       # the parent only starts the ranks (children, no exec) and passes their exit code on
+        import subprocess
+        sys.exit(subprocess.call(_plan["cmd"], env=_plan["env"]))
     main()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()

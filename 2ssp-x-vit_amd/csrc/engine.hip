@@ -92,7 +92,11 @@ struct ssp2_engine {
   long rows_cap = 0;        // token-matrix rows the workspace is sized for
   hipStream_t stream = nullptr;
   int n_cu = 256;
+  int dev = 0;             // HIP device the engine was created on
   int zig = 0;             // direction of the next large launch (next_dir)
+  // Run-time switches (ssp2_set_option).  Their defaults are read from the environment ONCE, in ssp2_create (round 2 called
+  // getenv on every launch); tests and A/B scripts flip them per handle.
+  int opt[SSP2_OPT_COUNT] = {};
   std::vector<void*> allocs;
   size_t ws_bytes = 0, weight_bytes = 0;
 
@@ -115,11 +119,23 @@ struct ssp2_engine {
   float* stage_f32 = nullptr;   // staging buffer of ssp2_load_tensor (host sources)
   size_t stage_cap = 0;
 
-  // profiling
+  // ssp2_prune_ffn scratch (allocated at the first call, sized for the widest block: later calls allocate nothing)
+  bf16 *prune_t1 = nullptr, *prune_t2 = nullptr;
+  float* prune_tb = nullptr;
+  int* prune_keep = nullptr;
+  size_t prune_t1_cap = 0, prune_t2_cap = 0, prune_tb_cap = 0, prune_keep_cap = 0;
+
+  // profiling: prof_class = one SSP2_K_* class, SSP2_K_COUNT = every class, -1 = off
   int prof_class = -1;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-  double prof_flops = 0;   // algorithmic 2*M*N*K of the recorded GEMM launches
+  struct ProfEvent { hipEvent_t a, b; int klass; };
+  std::vector<ProfEvent> prof_events;
+  double prof_flops[SSP2_K_COUNT] = {};   // algorithmic flops of the recorded launches (2*M*N*K; attention: 4*N*N*d_h per head and image)
+  double prof_bytes[SSP2_K_COUNT] = {};   // algorithmic HBM bytes of the recorded launches (the memory-bound classes)
 };
+
+// hipFuncSetAttribute state is per DEVICE (round 2 kept one flag per process: wrong the moment one process drives two GPUs)
+static const int kMaxDevices = 64;
+static inline int cur_device() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices) ? d : 0; }
 
 template <typename T>
 static int dalloc(ssp2_engine* e, T** p, size_t count, bool workspace) {
@@ -151,18 +167,18 @@ static int mat_alloc(ssp2_engine* e, Mat& m, int rows, int cols) {
 // 320 images).  Results do not depend on the order.  Same-box A/B, three boxes: -0.8 % of the step
 // (profiles/r02_f_zigzag_ab.txt); SSP2_ZIGZAG=0 switches it off.
 static int next_dir(ssp2_engine* e) {
-  const char* v = getenv("SSP2_ZIGZAG");                       // read per launch: the GPU test flips it inside one process
-  if (v && v[0] == '0') return 0;
+  if (!e->opt[SSP2_OPT_ZIGZAG]) return 0;
   const int d = e->zig; e->zig ^= 1; return d;
 }
 
 struct ProfScope {
-  ssp2_engine* e; bool on; hipEvent_t a{}, b{};
-  ProfScope(ssp2_engine* e_, int klass, double flops = 0) : e(e_), on(e_->prof_class == klass) {
-    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, e->stream); e->prof_flops += flops; }
+  ssp2_engine* e; bool on; int klass; hipEvent_t a{}, b{};
+  ProfScope(ssp2_engine* e_, int klass_, double flops = 0, double bytes = 0)
+      : e(e_), on(klass_ >= 0 && klass_ < SSP2_K_COUNT && (e_->prof_class == klass_ || e_->prof_class == SSP2_K_COUNT)), klass(klass_) {
+    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, e->stream); e->prof_flops[klass] += flops; e->prof_bytes[klass] += bytes; }
   }
   ~ProfScope() {
-    if (on) { hipEventRecord(b, e->stream); e->prof_events.emplace_back(a, b); }
+    if (on) { hipEventRecord(b, e->stream); e->prof_events.push_back({a, b, klass}); }
   }
 };
 
@@ -174,12 +190,13 @@ template <int EPI, int SCORE = 0, bool F8 = false>
 static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
-  g.group_m = 0;                 // plain N-fastest tile order (group_m means column groups here, see gemm256.hip.h)
+  // tile order: plain N-fastest unless SSP2_OPT_GROUP256 asks for column groups (100 * GM + GN, see gemm256.hip.h set_tile)
+  g.group_m = (EPI == EPI_RESID && SCORE > 0) ? 0 : e->opt[SSP2_OPT_GROUP256];
   if (F8 && (g.K % 128 || !g.wscale)) return fail(SSP2_EINVAL, "fp8 GEMM needs K %% 128 == 0 and per-row weight scales (K=%d)", g.K);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[kMaxDevices] = {};
+  if (!attr_done[e->dev]) {
     HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS));
-    attr_done = true;
+    attr_done[e->dev] = true;
   }
   if (!(EPI == EPI_RESID && SCORE > 0)) g.reverse = next_dir(e);
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
@@ -203,9 +220,9 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
 // cycles says the fused form is the cheaper one.  Returns dim / 256 or 0.
 static int ln_fusable(const ssp2_engine* e, int M, int K, bool f8) {
   const int D = e->d.dim;
-  const char* on = getenv("SSP2_LN_FUSION");
-  if (!on || on[0] == '0' || M < kBigTileMinRows || D % 256 || D / 256 < 3 || D / 256 > 5 || getenv("SSP2_NO_BIG_TILES")) return 0;
-  if (on[0] == '2') return D / 256;          // 2: always (tests: both residual projections of every layer)
+  const int on = e->opt[SSP2_OPT_LN_FUSION];
+  if (!on || M < kBigTileMinRows || D % 256 || D / 256 < 3 || D / 256 > 5 || !e->opt[SSP2_OPT_BIG_TILES]) return 0;
+  if (on == 2) return D / 256;               // 2: always (tests: both residual projections of every layer)
   const int tn = D / 256, tm = (M + 255) / 256, cu = e->n_cu;
   const int rounds_fused = (tm + cu - 1) / cu * tn, rounds_plain = (tm * tn + cu - 1) / cu;
   // cycles (≈1.86 GHz): a K-tile of the main loop 2.6 k (fp8: K-tiles of 128), tile change 9 k; the A panel's tn - 1 extra
@@ -234,8 +251,7 @@ template <int EPI, int SCORE = 0>
 static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
   if (g.K % GEMM_BK) return fail(SSP2_EINVAL, "GEMM K=%d not a multiple of %d", g.K, GEMM_BK);
   if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID || EPI == EPI_FC1) {
-    static const bool fc1_big = !getenv("SSP2_FC1_SMALL_TILES");
-    if (g.M >= kBigTileMinRows && !(EPI == EPI_FC1 && (g.out2 || !fc1_big)) && !getenv("SSP2_NO_BIG_TILES")) return launch_gemm256<EPI, SCORE>(e, g, klass);
+    if (g.M >= kBigTileMinRows && !(EPI == EPI_FC1 && (g.out2 || !e->opt[SSP2_OPT_FC1_BIG_TILES])) && e->opt[SSP2_OPT_BIG_TILES]) return launch_gemm256<EPI, SCORE>(e, g, klass);
   }
   return launch_gemm_small<EPI, SCORE>(e, g, klass);
 }
@@ -243,10 +259,10 @@ template <int EPI, int SCORE>
 static int launch_gemm_small(ssp2_engine* e, GemmArgs g, int klass) {
   g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
   if (g.tiles_m <= 0 || g.tiles_n <= 0) return fail(SSP2_EINVAL, "empty GEMM");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[kMaxDevices] = {};
+  if (!attr_done[e->dev]) {
     HIPCHK(hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI, SCORE>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    attr_done = true;
+    attr_done[e->dev] = true;
   }
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, SCORE>), dim3(g.tiles_m * g.tiles_n), dim3(256), GEMM_LDS_BYTES, e->stream, g);
@@ -256,7 +272,7 @@ static int launch_gemm_small(ssp2_engine* e, GemmArgs g, int klass) {
 
 static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const float* g, const float* b, bf16* y,
                      int out_ld, int rows, int D, RowMap gather = RowMap{0, 0, 0}, uint8_t* y8 = nullptr) {
-  ProfScope ps(e, SSP2_K_LN);
+  ProfScope ps(e, SSP2_K_LN, 0, (double)rows * D * (4.0 + (y8 ? 1.0 : 2.0)));     // fp32 row in, bf16 / e4m3 row out
   dim3 grid((rows + 3) / 4), blk(256);
   // one instantiation per row width in 256-element steps: the row lives in MAXV float4 registers per lane, and a
   // wider instantiation than needed drags predicated dead chunks along (ViT-L/16 on <8>: 3.1 TB/s; on <4>: see DESIGN)
@@ -282,22 +298,23 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
   constexpr int smem = DH == 64 ? NT * 32 * 256 + 4 * 4096
                      : (DH == 80 && (NT * 32 * 10) % 64 == 0) ? NT * 32 * 320 + 64
                      : NT * 32 * (DH * 2 + 16) + NT * 32 * 192;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[kMaxDevices] = {};
+  if (!attr_done[e->dev]) {
     HIPCHK(hipFuncSetAttribute((const void*)attn_fwd_kernel<DH, NT, CLS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
+    attr_done[e->dev] = true;
   }
-  ProfScope ps(e, SSP2_K_ATTN);
   const int D = e->d.dim, ld = 3 * D;
+  // algorithmic work of a full attention: S = QK^T and O = PV, 2 * N * N * d_h flops each per (image, head); q, k, v read, o written
+  const double qn = CLS ? 1.0 : (double)e->tokens;
+  ProfScope ps(e, SSP2_K_ATTN, 4.0 * qn * e->tokens * DH * e->d.heads * n, 2.0 * n * D * (2.0 * e->tokens + 2.0 * qn));
   if constexpr (DH == 64 && !CLS && NT >= 4 && NT <= 7) {
-    // persistent producer / consumer form (attn.hip.h); SSP2_ATTN_PERSIST=0 keeps the one-item-per-workgroup kernel
-    const char* pv = getenv("SSP2_ATTN_PERSIST");              // read per launch: the A/B test flips it inside one process
-    if (!pv || atoi(pv) != 0) {
+    // persistent producer / consumer form (attn.hip.h); SSP2_OPT_ATTN_PERSIST = 0 keeps the one-item-per-workgroup kernel
+    if (e->opt[SSP2_OPT_ATTN_PERSIST]) {
       constexpr int psmem = 2 * 2 * NT * 32 * 128 + 7 * 4096;
-      static bool pattr_done = false;
-      if (!pattr_done) {
+      static bool pattr_done[kMaxDevices] = {};
+      if (!pattr_done[e->dev]) {
         HIPCHK(hipFuncSetAttribute((const void*)attn64_persist_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, psmem));
-        pattr_done = true;
+        pattr_done[e->dev] = true;
       }
       const long items = (long)e->d.heads * n;
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
@@ -359,6 +376,16 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
   {
     int dev = 0; hipDeviceProp_t pr;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) e->n_cu = pr.multiProcessorCount;
+    e->dev = (dev >= 0 && dev < kMaxDevices) ? dev : 0;
+  }
+  {   // option defaults, each overridable ONCE by its environment variable (read here, never on a launch path)
+    auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
+    e->opt[SSP2_OPT_ZIGZAG] = env_int("SSP2_ZIGZAG", 1);
+    e->opt[SSP2_OPT_ATTN_PERSIST] = env_int("SSP2_ATTN_PERSIST", 1);
+    e->opt[SSP2_OPT_LN_FUSION] = env_int("SSP2_LN_FUSION", 0);
+    e->opt[SSP2_OPT_BIG_TILES] = getenv("SSP2_NO_BIG_TILES") ? 0 : 1;
+    e->opt[SSP2_OPT_FC1_BIG_TILES] = getenv("SSP2_FC1_SMALL_TILES") ? 0 : 1;
+    e->opt[SSP2_OPT_GROUP256] = env_int("SSP2_GROUP256", 0);
   }
   e->d_int.assign(d.d_int, d.d_int + d.depth);
   e->d.d_int = e->d_int.data();
@@ -420,8 +447,9 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
 int ssp2_destroy(ssp2_handle e) {
   if (!e) return 0;
   hipStreamSynchronize(e->stream);
-  for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  for (auto& pr : e->prof_events) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
   for (void* p : e->allocs) hipFree(p);
+  hipFree(e->prune_t1); hipFree(e->prune_t2); hipFree(e->prune_tb); hipFree(e->prune_keep);
   if (e->stage_f32) hipFree(e->stage_f32);
   delete e;
   return 0;
@@ -440,6 +468,18 @@ int ssp2_set_cu_limit(ssp2_handle e, int n_cu) {
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) phys = pr.multiProcessorCount;
   e->n_cu = (n_cu <= 0 || n_cu > phys) ? phys : n_cu;
   return 0;
+}
+int ssp2_set_option(ssp2_handle e, int option, int value) {
+  if (!e) return fail(SSP2_EINVAL, "null handle");
+  if (option < 0 || option >= SSP2_OPT_COUNT) return fail(SSP2_EINVAL, "unknown option %d", option);
+  if (option == SSP2_OPT_LN_FUSION && (value < 0 || value > 2)) return fail(SSP2_EINVAL, "SSP2_OPT_LN_FUSION takes 0, 1 or 2");
+  if (option == SSP2_OPT_GROUP256 && value < 0) return fail(SSP2_EINVAL, "SSP2_OPT_GROUP256 takes 100 * GM + GN >= 0");
+  e->opt[option] = value;
+  return 0;
+}
+int ssp2_get_option(ssp2_handle e, int option) {
+  if (!e || option < 0 || option >= SSP2_OPT_COUNT) return fail(SSP2_EINVAL, "bad option query");
+  return e->opt[option];
 }
 int ssp2_tokens(ssp2_handle e) { return e ? e->tokens : SSP2_EINVAL; }
 int ssp2_query(ssp2_handle e, int what) {
@@ -823,14 +863,34 @@ int ssp2_prune_ffn(ssp2_handle e, int layer, const int32_t* keep, int n_keep) {
   if (!(L.fc1.w_set && L.fc1.b_set && L.fc2.w_set)) return fail(SSP2_ESTATE, "layer %d MLP weights not loaded", layer);
   const int D = e->d.dim;
   const int new_ld = ceil_to(n_keep, GEMM_BK);
-  int* keep_dev = nullptr;
-  bf16 *t1 = nullptr, *t2 = nullptr;
-  float* tb = nullptr;
   const size_t fc1_elems = (size_t)L.fc1.rows_pad * L.fc1.ld, fc2_elems = (size_t)L.fc2.rows_pad * new_ld;
-  HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipMalloc(&keep_dev, (size_t)n_keep * 4));
-  HIPCHK(hipMalloc(&t1, fc1_elems * 2)); HIPCHK(hipMalloc(&t2, fc2_elems * 2)); HIPCHK(hipMalloc(&tb, (size_t)L.fc1.rows_pad * 4));
-  HIPCHK(hipMemcpy(keep_dev, keep, (size_t)n_keep * 4, hipMemcpyHostToDevice));
+  // Scratch of the in-place gather lives in the engine: allocated at the first call for the WIDEST block (every later call,
+  // on any layer, fits), so a prune is stream-ordered device work — no hipMalloc / hipFree, no stream synchronisation
+  // (round 2: four of each per block and two synchronisations).  The pageable keep list is staged by the runtime before
+  // hipMemcpyAsync returns.
+  auto grow = [&](auto** p, size_t& cap, size_t want, size_t worst) -> int {
+    if (cap >= want) return 0;
+    HIPCHK(hipStreamSynchronize(e->stream));        // (only when a buffer must be replaced: work in flight may still read it)
+    if (*p) hipFree(*p);
+    *p = nullptr; cap = 0;
+    const size_t n = std::max(want, worst);
+    HIPCHK(hipMalloc((void**)p, n * sizeof(**p)));
+    cap = n;
+    return 0;
+  };
+  size_t worst1 = 0, worst2 = 0, worstb = 0, worstk = 0;
+  for (const Layer& Lx : e->layers) {
+    worst1 = std::max(worst1, (size_t)Lx.fc1.rows_pad * Lx.fc1.ld); worst2 = std::max(worst2, (size_t)Lx.fc2.rows_pad * Lx.fc2.ld);
+    worstb = std::max(worstb, (size_t)Lx.fc1.rows_pad); worstk = std::max(worstk, (size_t)Lx.d_int);
+  }
+  int rc0;
+  if ((rc0 = grow(&e->prune_t1, e->prune_t1_cap, fc1_elems, worst1)) || (rc0 = grow(&e->prune_t2, e->prune_t2_cap, fc2_elems, worst2)) ||
+      (rc0 = grow(&e->prune_tb, e->prune_tb_cap, (size_t)L.fc1.rows_pad, worstb)) || (rc0 = grow(&e->prune_keep, e->prune_keep_cap, (size_t)n_keep, worstk)))
+    return rc0;
+  int* const keep_dev = e->prune_keep;
+  bf16 *const t1 = e->prune_t1, *const t2 = e->prune_t2;
+  float* const tb = e->prune_tb;
+  HIPCHK(hipMemcpyAsync(keep_dev, keep, (size_t)n_keep * 4, hipMemcpyHostToDevice, e->stream));
   // fc1: rows gathered, same leading dimension (K = dim); fc2: columns gathered into the new, smaller leading dimension
   hipLaunchKernelGGL(gather_matrix_kernel, dim3(2048), dim3(256), 0, e->stream, L.fc1.w, L.fc1.ld, t1, L.fc1.ld, L.fc1.rows_pad, n_keep, D, keep_dev, (const int*)nullptr);
   hipLaunchKernelGGL(gather_vector_kernel, dim3((L.fc1.rows_pad + 255) / 256), dim3(256), 0, e->stream, L.fc1.b, tb, L.fc1.rows_pad, n_keep, keep_dev);
@@ -839,15 +899,12 @@ int ssp2_prune_ffn(ssp2_handle e, int layer, const int32_t* keep, int n_keep) {
   HIPCHK(hipMemcpyAsync(L.fc1.w, t1, fc1_elems * 2, hipMemcpyDeviceToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(L.fc1.b, tb, (size_t)L.fc1.rows_pad * 4, hipMemcpyDeviceToDevice, e->stream));
   HIPCHK(hipMemcpyAsync(L.fc2.w, t2, fc2_elems * 2, hipMemcpyDeviceToDevice, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  hipFree(keep_dev); hipFree(t1); hipFree(t2); hipFree(tb);
   L.d_int = n_keep; L.ld_int = new_ld;
   L.fc1.rows = n_keep; L.fc2.cols = n_keep; L.fc2.ld = new_ld;
   e->d_int[layer] = n_keep;
   if (e->fp8) {                                  // fresh e4m3 images (and row scales) of the compacted matrices
     int rc;
     if ((rc = quantise_mat(e, L.fc1)) || (rc = quantise_mat(e, L.fc2))) return rc;
-    HIPCHK(hipStreamSynchronize(e->stream));
   }
   return 0;
 }
@@ -933,7 +990,8 @@ int ssp2_linear_bf16(void* hip_stream, int epilogue, const uint16_t* a_dev, int 
     n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
   }
   ssp2_engine e;
-  e.stream = (hipStream_t)hip_stream; e.n_cu = n_cu;
+  e.stream = (hipStream_t)hip_stream; e.n_cu = n_cu; e.dev = cur_device();
+  e.opt[SSP2_OPT_BIG_TILES] = e.opt[SSP2_OPT_FC1_BIG_TILES] = 1;
   GemmArgs g{};
   g.A = (const bf16*)a_dev; g.lda = lda; g.W = (const bf16*)w_dev; g.ldw = ldw; g.bias = bias_dev;
   g.M = M; g.N = N; g.K = K; g.tiles_n = ceil_to(N, 256) / GEMM_BN;
@@ -954,27 +1012,46 @@ int ssp2_linear_bf16(void* hip_stream, int epilogue, const uint16_t* a_dev, int 
 }
 
 int ssp2_profile_begin(ssp2_handle e, int klass) {
-  if (!e || klass < 0 || klass >= SSP2_K_COUNT) return fail(SSP2_EINVAL, "bad profile class");
-  for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  if (!e || klass < 0 || klass > SSP2_K_COUNT) return fail(SSP2_EINVAL, "bad profile class");      // SSP2_K_COUNT = every class
+  for (auto& pr : e->prof_events) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
   e->prof_events.clear();
-  e->prof_flops = 0;
+  for (int k = 0; k < SSP2_K_COUNT; ++k) e->prof_flops[k] = e->prof_bytes[k] = 0;
   e->prof_class = klass;
+  return 0;
+}
+
+// per-class totals of the launches recorded since ssp2_profile_begin (synchronises the stream; leaves the recording on)
+int ssp2_profile_query(ssp2_handle e, int klass, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+  if (!e || klass < 0 || klass >= SSP2_K_COUNT) return fail(SSP2_EINVAL, "bad profile class");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  double tot = 0; int64_t cnt = 0;
+  for (auto& pr : e->prof_events) {
+    if (pr.klass != klass) continue;
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, pr.a, pr.b));
+    tot += ms; ++cnt;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = cnt;
+  if (flops) *flops = e->prof_flops[klass];
+  if (bytes) *bytes = e->prof_bytes[klass];
   return 0;
 }
 
 int ssp2_profile_end(ssp2_handle e, double* total_ms, int64_t* launches, double* gemm_flops) {
   if (!e) return fail(SSP2_EINVAL, "null handle");
   HIPCHK(hipStreamSynchronize(e->stream));
-  double tot = 0;
+  double tot = 0, fl = 0;
   for (auto& pr : e->prof_events) {
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+    HIPCHK(hipEventElapsedTime(&ms, pr.a, pr.b));
     tot += ms;
-    hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+    hipEventDestroy(pr.a); hipEventDestroy(pr.b);
   }
+  for (int k = 0; k < SSP2_K_COUNT; ++k) fl += e->prof_flops[k];
   if (total_ms) *total_ms = tot;
   if (launches) *launches = (int64_t)e->prof_events.size();
-  if (gemm_flops) *gemm_flops = e->prof_flops;
+  if (gemm_flops) *gemm_flops = fl;
   e->prof_events.clear();
   e->prof_class = -1;
   return 0;

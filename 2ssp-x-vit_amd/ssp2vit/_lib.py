@@ -13,13 +13,13 @@ CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libssp2vit.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 
-ABI_VERSION = 2                                         # SSP2_ABI_VERSION of include/ssp2vit.h
+ABI_VERSION = 3                                         # SSP2_ABI_VERSION of include/ssp2vit.h
 
 # every symbol include/ssp2vit.h declares
 SYMBOLS = [
     "ssp2_abi_version", "ssp2_last_error", "ssp2_create", "ssp2_destroy", "ssp2_set_stream", "ssp2_load_tensor",
     "ssp2_load_tensor_dev", "ssp2_linear_bf16", "ssp2_query", "ssp2_restore_attention", "ssp2_clone_weights",
-    "ssp2_prune_ffn_into", "ssp2_set_precision", "ssp2_set_cu_limit",
+    "ssp2_prune_ffn_into", "ssp2_set_precision", "ssp2_set_cu_limit", "ssp2_set_option", "ssp2_get_option", "ssp2_profile_query",
     "ssp2_embed", "ssp2_layers", "ssp2_head", "ssp2_tail", "ssp2_prune_ffn", "ssp2_drop_attention", "ssp2_d_int", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
     "ssp2_tokens", "ssp2_rows", "ssp2_workspace_bytes", "ssp2_preproc_create", "ssp2_preproc_run", "ssp2_preproc_destroy",
 ]
@@ -28,6 +28,7 @@ T_KINDS = ["patch_w", "patch_b", "cls", "pos", "ln1_g", "ln1_b", "qkv_w", "qkv_b
            "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "lnf_g", "lnf_b", "head_w", "head_b"]
 SCORE_SITE = {"none": 0, "pre_gelu": 1, "post_gelu": 2}
 SCORE_CHAIN = {"fp32": 0, "bf16_ref": 1}
+OPTIONS = {"zigzag": 0, "attn_persist": 1, "ln_fusion": 2, "big_tiles": 3, "fc1_big_tiles": 4, "group256": 5}   # SSP2_OPT_*
 K_CLASS = {"gemm_fc1": 0, "gemm_fc2": 1, "gemm_qkv": 2, "gemm_proj": 3, "gemm_patch": 4, "gemm_head": 5,
            "attn": 6, "ln": 7, "score_finish": 8, "act_l2": 9, "other": 10}
 
@@ -201,6 +202,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_act_l2_accum.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, C.c_size_t]
     lib.ssp2_profile_begin.argtypes = [vp, i32]
     lib.ssp2_profile_end.argtypes = [vp, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double)]
+    lib.ssp2_profile_query.argtypes = [vp, i32, C.POINTER(C.c_double), i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.ssp2_set_option.argtypes = [vp, i32, i32]
+    lib.ssp2_get_option.argtypes = [vp, i32]
     lib.ssp2_tokens.argtypes = [vp]
     lib.ssp2_query.argtypes = [vp, i32]
     lib.ssp2_set_precision.argtypes = [vp, i32]

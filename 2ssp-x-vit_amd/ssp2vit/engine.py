@@ -9,7 +9,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import K_CLASS, SCORE_CHAIN, SCORE_SITE, T_KINDS, Ssp2Error, VitDesc, check
+from ._lib import K_CLASS, OPTIONS, SCORE_CHAIN, SCORE_SITE, T_KINDS, Ssp2Error, VitDesc, check
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -124,6 +124,17 @@ class VitEngine:
     def set_cu_limit(self, n_cu: int) -> None:
         """Cap the grids of this engine's persistent kernels at n_cu workgroups (0 = all CUs)."""
         check(self.lib.ssp2_set_cu_limit(self.h, int(n_cu)))
+
+    def set_option(self, name: str, value: int) -> None:
+        """Run-time switch of this engine (include/ssp2vit.h SSP2_OPT_*: "zigzag", "attn_persist", "ln_fusion", "big_tiles",
+        "fc1_big_tiles", "group256").  None of them changes a result bit; they exist for the tests and A/B scripts that prove it."""
+        check(self.lib.ssp2_set_option(self.h, OPTIONS[name], int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = self.lib.ssp2_get_option(self.h, OPTIONS[name])
+        if v < 0:
+            check(v)
+        return int(v)
 
     def pruned_twin(self, d_int: Sequence[int], max_images: int = 64) -> "VitEngine":
         """A second engine of the same architecture with FFN widths `d_int`, every other weight cloned device to
@@ -282,16 +293,25 @@ class VitEngine:
         return torch.cat(outs, 0)
 
     def profile(self, klass: str):
+        """HIP events around every launch of one kernel class ("gemm_fc1", ...) or of every class ("all"); after the block:
+        .total_ms / .launches / .flops, and with "all" also .by_class[name] = dict(ms, launches, flops, bytes)."""
         eng = self
 
         class _Ctx:
             def __enter__(self_inner):
                 eng._bind_stream()
-                check(eng.lib.ssp2_profile_begin(eng.h, K_CLASS[klass]))
+                check(eng.lib.ssp2_profile_begin(eng.h, len(K_CLASS) if klass == "all" else K_CLASS[klass]))
                 return self_inner
 
             def __exit__(self_inner, *exc):
                 ms, cnt, fl = C.c_double(), C.c_int64(), C.c_double()
+                if klass == "all":
+                    self_inner.by_class = {}
+                    for name, k in K_CLASS.items():
+                        by = C.c_double()
+                        check(eng.lib.ssp2_profile_query(eng.h, k, C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by)))
+                        if cnt.value:
+                            self_inner.by_class[name] = {"ms": ms.value, "launches": cnt.value, "flops": fl.value, "bytes": by.value}
                 check(eng.lib.ssp2_profile_end(eng.h, C.byref(ms), C.byref(cnt), C.byref(fl)))
                 self_inner.total_ms, self_inner.launches, self_inner.flops = ms.value, cnt.value, fl.value
                 return False

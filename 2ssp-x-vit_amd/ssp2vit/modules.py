@@ -75,6 +75,11 @@ class EngineViT(nn.Module):
                 put(b.mlp.fc2.weight, w[f"fc2_w.{i}"]); put(b.mlp.fc2.bias, w[f"fc2_b.{i}"])
             put(self.norm.weight, w["lnf_g"]); put(self.norm.bias, w["lnf_b"])
             put(self.head.weight, w["head_w"]); put(self.head.bias, w["head_b"])
+        for i, b in enumerate(self.blocks):              # a checkpoint saved after stage 2: those blocks have no attention
+            if w.get(f"attn_absent.{i}"):
+                b.attn = _vp.TimmAttentionBypass()
+        if w.get("layout") in ("hf", "hf5"):           # weights converted from an HF checkpoint: the reference's hook site there
+            self.ssp2_score_site = "post_gelu"
         self.eval()
 
     @torch.no_grad()

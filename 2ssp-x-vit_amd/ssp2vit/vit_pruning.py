@@ -187,7 +187,9 @@ def _compute_ffn_activation_importance(vit_model, dataloader, device: str = "cud
     vit_model.eval()
     _, kind = _blocks(vit_model)                # raises AttributeError on unknown anatomy like the reference
     d_ints = [p[0].out_features for p in _gather_mlp_pairs(vit_model)]
-    site = _weights.score_site_for("timm" if kind == "timm" else "hf")
+    # a container built from a CONVERTED checkpoint (modules.EngineViT over an HF state dict) keeps the hook site of the
+    # anatomy the weights came from: the reference would have hooked the HF module post-GELU (:135)
+    site = getattr(vit_model, "ssp2_score_site", None) or _weights.score_site_for("timm" if kind == "timm" else "hf")
     return _core.stage1_scores(_engine_factory(vit_model, device, engine), dataloader, d_ints, site,
                                batch_limit=batch_limit, progress=progress, score_chain=score_chain,
                                process_group=process_group, defer=defer, sharded=sharded)

@@ -218,3 +218,133 @@ def from_module(model) -> Dict:
     w.update(img=side * patch, patch=patch, dim=dim, heads=heads, depth=depth,
              classes=int(w["head_w"].shape[0]), eps=eps, layout=layout)
     return w
+
+
+# ----------------------------------------------------------------------------- local checkpoints (CLI --weights)
+_KNOWN_HEADS = {192: 3, 384: 6, 768: 12, 1024: 16, 1280: 16}       # ViT-Ti / S / B / L / H: the published geometries
+
+
+def from_state_dict(sd: Dict[str, torch.Tensor], config: Optional[Dict] = None, meta: Optional[Dict] = None) -> Dict:
+    """Flat dictionary from a checkpoint's state dict in any of the three key layouts `from_module` reads from live
+    modules: timm (`blocks.N.attn.qkv.weight`, ...), transformers < 5 (`vit.encoder.layer.N.attention.attention.query...`)
+    and transformers >= 5 (`vit.layers.N.attention.q_proj...`; also under `vit.encoder.layers`).  `config` = the HF
+    config.json (heads, layer_norm_eps); `meta` = this build's pruning_meta.json (bypassed attention blocks).  FFN widths
+    come from the tensor shapes, so a width-pruned checkpoint loads as it is.  The reference loads its models with
+    `from_pretrained` / `timm.create_model` + `load_state_dict` (adaptation-for-Pures-framework/auto_2ssp.py:636-667);
+    neither library's model code is needed here."""
+    config, meta = dict(config or {}), dict(meta or {})
+    f = lambda k: sd[k].detach().to(torch.float32).contiguous()
+    has = lambda k: k in sd
+    opt = lambda k, n: f(k) if has(k) else torch.zeros(n)
+    w: Dict = {}
+    absent = set(int(i) for i in meta.get("attention_removed_blocks", []))
+    if has("patch_embed.proj.weight"):                                   # ---- timm
+        layout = "timm"
+        w["patch_w"], w["patch_b"] = f("patch_embed.proj.weight"), f("patch_embed.proj.bias")
+        w["cls"], w["pos"] = f("cls_token"), f("pos_embed")
+        dim = int(w["patch_w"].shape[0])
+        i = 0
+        while has(f"blocks.{i}.norm1.weight"):
+            p = f"blocks.{i}."
+            w[f"ln1_g.{i}"], w[f"ln1_b.{i}"] = f(p + "norm1.weight"), f(p + "norm1.bias")
+            if has(p + "attn.qkv.weight"):
+                w[f"qkv_w.{i}"], w[f"qkv_b.{i}"] = f(p + "attn.qkv.weight"), opt(p + "attn.qkv.bias", 3 * dim)
+                w[f"proj_w.{i}"], w[f"proj_b.{i}"] = f(p + "attn.proj.weight"), opt(p + "attn.proj.bias", dim)
+            else:
+                absent.add(i)
+            w[f"ln2_g.{i}"], w[f"ln2_b.{i}"] = f(p + "norm2.weight"), f(p + "norm2.bias")
+            w[f"fc1_w.{i}"], w[f"fc1_b.{i}"] = f(p + "mlp.fc1.weight"), f(p + "mlp.fc1.bias")
+            w[f"fc2_w.{i}"], w[f"fc2_b.{i}"] = f(p + "mlp.fc2.weight"), f(p + "mlp.fc2.bias")
+            i += 1
+        w["lnf_g"], w["lnf_b"] = f("norm.weight"), f("norm.bias")
+        w["head_w"], w["head_b"] = f("head.weight"), f("head.bias")
+        eps = float(config.get("layer_norm_eps", 1e-6))
+    else:
+        pre = "vit." if any(k.startswith("vit.") for k in sd) else ""
+        emb = pre + "embeddings."
+        if not has(emb + "patch_embeddings.projection.weight"):
+            raise AttributeError("Unsupported ViT checkpoint: neither timm (patch_embed.proj) nor HF (embeddings.patch_embeddings) keys")
+        w["patch_w"], w["patch_b"] = f(emb + "patch_embeddings.projection.weight"), f(emb + "patch_embeddings.projection.bias")
+        w["cls"], w["pos"] = f(emb + "cls_token"), f(emb + "position_embeddings")
+        dim = int(w["patch_w"].shape[0])
+        if has(pre + "encoder.layer.0.layernorm_before.weight"):        # ---- transformers < 5
+            layout, base = "hf", pre + "encoder.layer."
+        else:                                                           # ---- transformers >= 5
+            layout = "hf5"
+            base = pre + ("layers." if has(pre + "layers.0.layernorm_before.weight") else "encoder.layers.")
+        i = 0
+        while has(f"{base}{i}.layernorm_before.weight"):
+            p = f"{base}{i}."
+            w[f"ln1_g.{i}"], w[f"ln1_b.{i}"] = f(p + "layernorm_before.weight"), f(p + "layernorm_before.bias")
+            if layout == "hf":
+                q, k_, v, o = (p + "attention.attention.query", p + "attention.attention.key", p + "attention.attention.value",
+                               p + "attention.output.dense")
+                fc1, fc2 = p + "intermediate.dense", p + "output.dense"
+            else:
+                q, k_, v, o = p + "attention.q_proj", p + "attention.k_proj", p + "attention.v_proj", p + "attention.o_proj"
+                fc1, fc2 = p + "mlp.fc1", p + "mlp.fc2"
+            if has(q + ".weight"):
+                w[f"qkv_w.{i}"] = torch.cat([f(q + ".weight"), f(k_ + ".weight"), f(v + ".weight")], 0)
+                w[f"qkv_b.{i}"] = torch.cat([opt(q + ".bias", dim), opt(k_ + ".bias", dim), opt(v + ".bias", dim)], 0)
+                w[f"proj_w.{i}"], w[f"proj_b.{i}"] = f(o + ".weight"), opt(o + ".bias", dim)
+            else:
+                absent.add(i)
+            w[f"ln2_g.{i}"], w[f"ln2_b.{i}"] = f(p + "layernorm_after.weight"), f(p + "layernorm_after.bias")
+            w[f"fc1_w.{i}"], w[f"fc1_b.{i}"] = f(fc1 + ".weight"), f(fc1 + ".bias")
+            w[f"fc2_w.{i}"], w[f"fc2_b.{i}"] = f(fc2 + ".weight"), f(fc2 + ".bias")
+            i += 1
+        w["lnf_g"], w["lnf_b"] = f(pre + "layernorm.weight"), f(pre + "layernorm.bias")
+        w["head_w"], w["head_b"] = f("classifier.weight"), f("classifier.bias")
+        eps = float(config.get("layer_norm_eps", 1e-12))
+    depth = i
+    if depth == 0:
+        raise AttributeError("Unsupported ViT checkpoint: no encoder blocks found")
+    heads = config.get("num_attention_heads", meta.get("num_attention_heads"))
+    if heads is None:
+        heads = _KNOWN_HEADS.get(dim)
+    if heads is None:
+        raise AttributeError(f"cannot determine the number of attention heads for hidden size {dim}: give config.json "
+                             "(num_attention_heads) or --heads")
+    for b in range(depth):
+        if b in absent:
+            w[f"attn_absent.{b}"] = True
+            w[f"qkv_w.{b}"] = torch.zeros(3 * dim, dim); w[f"qkv_b.{b}"] = torch.zeros(3 * dim)
+            w[f"proj_w.{b}"] = torch.zeros(dim, dim); w[f"proj_b.{b}"] = torch.zeros(dim)
+    patch = int(w["patch_w"].shape[-1])
+    side = int(round(math.sqrt(int(w["pos"].shape[1]) - 1)))
+    w.update(img=side * patch, patch=patch, dim=dim, heads=int(heads), depth=depth, classes=int(w["head_w"].shape[0]),
+             eps=eps, layout=layout)
+    return w
+
+
+def load_checkpoint(path: str, heads: Optional[int] = None) -> Dict:
+    """CLI `--weights`: a LOCAL checkpoint -> the flat dictionary.  Accepted: a `.safetensors` file, a `.pth` / `.pt` /
+    `.bin` state dict (loaded with `weights_only=True`: nothing in the file is executed), or a directory holding
+    `model.safetensors` / `pytorch_model.bin` / `timm_model.pth` with an optional `config.json` and this build's
+    `pruning_meta.json` — i.e. an HF `save_pretrained` directory, or what `ssp2vit.export` writes.  No network access."""
+    import json
+    import os
+    config, meta = {}, {}
+    file = path
+    if os.path.isdir(path):
+        for name in ("model.safetensors", "pytorch_model.bin", "timm_model.pth"):
+            if os.path.exists(os.path.join(path, name)):
+                file = os.path.join(path, name)
+                break
+        else:
+            raise FileNotFoundError(f"{path}: no model.safetensors / pytorch_model.bin / timm_model.pth inside")
+        for name, dst in (("config.json", config), ("pruning_meta.json", meta)):
+            p = os.path.join(path, name)
+            if os.path.exists(p):
+                with open(p, encoding="utf-8") as fh:
+                    dst.update(json.load(fh))
+    if file.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        sd = load_file(file)
+    else:
+        sd = torch.load(file, map_location="cpu", weights_only=True)
+        if isinstance(sd, dict) and "state_dict" in sd and not any(torch.is_tensor(v) for v in sd.values()):
+            sd = sd["state_dict"]
+    if heads is not None:
+        config["num_attention_heads"] = int(heads)
+    return from_state_dict(sd, config, meta)

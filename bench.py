@@ -41,15 +41,69 @@ for p in (ROOT, os.path.join(ROOT, "2ssp-x-vit_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+
+# ------------------------------------------------------------------------------------------------ self-launch (N > 1)
+def launcher_plan(argv, environ):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: the command line and environment of
+    the N-rank job this process should START (one process per GPU over RCCL), or None when this process is itself a rank
+    (RANK / WORLD_SIZE set: started by torch.distributed.run, e.g. by the driver) or N == 1.  Pure function of its
+    arguments — the parent never imports torch, so it never initialises HIP before (or after) the children exist."""
+    import socket
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "RANK" in environ or "WORLD_SIZE" in environ:
+        return None
+    port = environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__), *argv]
+    return {"cmd": cmd, "env": env, "n": n}
+
+
+def run_launcher(plan) -> int:
+    """Start the N ranks as CHILD processes (no exec), relay their output, return the job's exit code; non-zero when any
+    rank failed or rank 0 printed no result line."""
+    import subprocess
+    proc = subprocess.Popen(plan["cmd"], env=plan["env"], stdout=subprocess.PIPE, text=True, bufsize=1)
+    got_line = False
+    for line in proc.stdout:
+        sys.stdout.write(line); sys.stdout.flush()
+        if line.lstrip().startswith("{") and '"metric"' in line:
+            got_line = True
+    rc = proc.wait()
+    if rc == 0 and not got_line:
+        print("bench.py launcher: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        return 1
+    return rc
+
+
+if __name__ == "__main__":
+    _plan = launcher_plan(sys.argv[1:], os.environ)
+    if _plan is not None:
+        sys.exit(run_launcher(_plan))
+
 import torch  # noqa: E402
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 FP8_MFMA_PEAK_TFLOPS = 5000.0    # dense, same table ("Peak FP8 MFMA")
 
 
-def _newest_summary(pattern):
-    """Newest committed PMC summary of that kind whose recorded library source hash equals the running library's
-    (counters cannot be read from inside the process; a summary of another kernel revision is not evidence)."""
+def _newest_summary(pattern, model="vit_base_patch16_224", precision="bf16"):
+    """Newest committed PMC summary of that kind recorded (a) at the running library's source hash — counters cannot be
+    read from inside the process, and a summary of another kernel revision is not evidence — and (b) on THIS model and
+    precision (round 2 keyed on the hash alone, so the ViT-L / ViT-H / fp8 lines carried ViT-B/16's busy fraction).
+    Summaries without the two fields predate them and were all taken on ViT-B/16 in bf16."""
     import glob
     from ssp2vit import _lib
     want = _lib._source_hash()
@@ -60,28 +114,70 @@ def _newest_summary(pattern):
                 js = json.load(f)
         except Exception:
             continue
+        if js.get("model", "vit_base_patch16_224") != model or js.get("precision", "bf16") != precision:
+            continue
         if js.get("lib_source_hash") == want:
             return js, os.path.basename(path), None
         stale = stale or os.path.basename(path)
     return None, None, stale
 
 
-def pmc_traffic():
-    js, name, stale = _newest_summary("r*_pmc_traffic.json")
+def pmc_traffic(model="vit_base_patch16_224", precision="bf16"):
+    js, name, stale = _newest_summary("r*_pmc_traffic*.json", model, precision)
     if js is None:
         return None, {"stale_summary_ignored": stale} if stale else None
     return int(js["fc1_family"]["avg_hbm_bytes_per_launch"]), {"source": name}
 
 
-def pmc_mfma():
-    js, name, stale = _newest_summary("r*_pmc_mfma.json")
+def pmc_mfma(model="vit_base_patch16_224", precision="bf16"):
+    js, name, stale = _newest_summary("r*_pmc_mfma*.json", model, precision)
     if js is None:
         return {"stale_summary_ignored": stale} if stale else None
     try:
         k = [r for r in js["kernels"] if "gemm256_bf16_kernel<2, 0" in r["kernel"]][0]
-        return {"mfma_busy_frac_of_cycles": k["mfma_util_of_cycles"], "shader_clock_ghz": k["shader_clock_ghz"], "source": name}
+        return {"mfma_busy_frac_of_cycles": k["mfma_util_of_cycles"], "shader_clock_ghz": k["shader_clock_ghz"], "source": name,
+                "model": model, "precision": precision}
     except Exception:
         return None
+
+
+FAMILIES = (("fc1", ("gemm_fc1",), "fc1 (+bias +erf-GELU; stage 1: + fused activation-L2 partials)"),
+            ("resid", ("gemm_fc2", "gemm_proj"), "attention out-projection + fc2 (+bias, fp32 residual read-add-write)"),
+            ("qkv", ("gemm_qkv",), "QKV projection (+bias)"),
+            ("attention", ("attn",), "softmax(QK^T / sqrt(d_h)) V per (image, head)"),
+            ("layernorm", ("ln",), "standalone LayerNorm (fp32 row in, bf16 / e4m3 row out)"),
+            ("other", ("gemm_patch", "gemm_head", "score_finish", "act_l2", "other"), "patch embed, head, score finish, argmax, im2col"))
+
+
+def roofline_by_family(by_class, precision):
+    """One extra, UNTIMED step with HIP events around every launch (VitEngine.profile("all")): per kernel family the
+    device time, its share, algorithmic flops / bytes and the fraction of the roofline that bounds it.  The GEMM families
+    on e4m3 operands are priced against the fp8 peak, the out-projection inside `resid` stays bf16 (priced as fp8 there:
+    a lower bound on the fraction)."""
+    tot = sum(v["ms"] for v in by_class.values()) or 1.0
+    peak = BF16_MFMA_PEAK_TFLOPS if precision == "bf16" else FP8_MFMA_PEAK_TFLOPS
+    out = {}
+    for name, classes, what in FAMILIES:
+        ms = sum(by_class.get(c, {}).get("ms", 0.0) for c in classes)
+        if ms <= 0:
+            continue
+        fl = sum(by_class.get(c, {}).get("flops", 0.0) for c in classes)
+        by = sum(by_class.get(c, {}).get("bytes", 0.0) for c in classes)
+        n = sum(by_class.get(c, {}).get("launches", 0) for c in classes)
+        row = {"kernels": what, "launches": int(n), "ms": round(ms, 3), "share_of_kernel_time": round(ms / tot, 4)}
+        if name in ("fc1", "resid", "qkv"):
+            tf = fl / (ms * 1e-3) / 1e12
+            row.update(bound="mfma", flops=fl, achieved=round(tf, 1), peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4))
+        elif name == "attention":
+            tf = fl / (ms * 1e-3) / 1e12
+            gb = by / (ms * 1e-3) / 1e9
+            row.update(bound="hbm", bytes=by, achieved=round(gb, 1), peak=8000.0, unit="GB/s", frac=round(gb / 8000.0, 4),
+                       flops=fl, tflops=round(tf, 1), frac_of_bf16_mfma_peak=round(tf / BF16_MFMA_PEAK_TFLOPS, 4))
+        elif name == "layernorm":
+            gb = by / (ms * 1e-3) / 1e9
+            row.update(bound="hbm", bytes=by, achieved=round(gb, 1), peak=8000.0, unit="GB/s", frac=round(gb / 8000.0, 4))
+        out[name] = row
+    return out
 
 
 def cpu_baseline(args, weights, n_eval, calib_n):
@@ -226,6 +322,8 @@ def main():
                          "so the roofline object is not a clean kernel figure)")
     ap.add_argument("--no-overlap-figure", action="store_true",
                     help="skip the secondary two-stream figure (profiled runs: its kernels would be counted with the step's)")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="no GPU work: the ranks meet over gloo and rank 0 prints a line with the world size (CPU test of --gpus N)")
     ap.add_argument("--overlap-stage1", action="store_true",
                     help="stage 1 on a second HIP stream (own engine workspace) BESIDE the layer-major search on the main one; "
                          "unlike --two-streams the search keeps its layer-major form and its candidates are not shared out")
@@ -236,6 +334,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.selftest_launcher:
+        import torch.distributed as dist
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            t = torch.ones(1); dist.all_reduce(t)
+            assert int(t) == world
+            dist.destroy_process_group()
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        if os.environ.get("SSP2_SELFTEST_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        if rank == 0:
+            print(json.dumps({"metric": "launcher_selftest", "n_gpus": world, "cuda_initialised": torch.cuda.is_initialized()}), flush=True)
+        return
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -333,7 +446,7 @@ def main():
         return out
     calib_loader, eval_loader = as_loader(calib), as_loader(evalb)            # this rank's batches only (sharded=True)
 
-    sdist.TIMING = args.config == 2 and pg is not None
+    sdist.TIMING = pg is not None              # device time of the exchange steps, both configs
 
     def step(s1_eng=eng1, sd=side, share=args.two_streams):
         # both stages are enqueued before the host waits for either: the a7 mask step runs on the CPU while the GPU
@@ -396,6 +509,13 @@ def main():
         prof.__exit__(None, None, None)
     coll = sdist.collective_ms() if sdist.TIMING else None
 
+    # every kernel family of the step: one more step, untimed, with HIP events around EVERY launch (the timed region above
+    # carries events on the fc1 family only, as in rounds 1-2, so `value` stays comparable)
+    families = None
+    if not args.no_roofline and not second:
+        with eng.profile("all") as pall:
+            step()
+        families = roofline_by_family(pall.by_class, args.precision)
     # stage-1-only rate (secondary figure, separate timed loop so the headline region stays untouched)
     sync_all(); t1 = time.perf_counter()
     core.stage1_scores(eng1, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg, chunk_images=calib_chunk, sharded=True)
@@ -464,13 +584,17 @@ def main():
             ach = prof.flops / (prof.total_ms * 1e-3) / 1e12
             peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else FP8_MFMA_PEAK_TFLOPS
             lm = f", x 1..{depth - 1} in the layer-major search" if args.batch_candidates else ""
-            traffic, tsrc = pmc_traffic()
+            traffic, tsrc = pmc_traffic(args.model, args.precision)
             line["roofline"] = {"bound": "mfma", "kernel": "fc1 GEMM family: gemm256 persistent 256x256 <EPI_FC1,SCORE> (stage 1: + fused activation-L2 partials; search passes: SCORE=0) and gemm_bf16_kernel<EPI_FC1> 128x128 (CLS tail); bias + erf-GELU fused",
                                 "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc, "pmc": pmc_mfma(),
+                                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc, "pmc": pmc_mfma(args.model, args.precision),
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
                                 "flops_per_launch_avg": prof.flops / prof.launches,
                                 "shapes": f"[{eng.rows(min(n_calib, calib_chunk), args.batch)} | {eval_chunk * tokens} | {eval_chunk}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk{lm} | CLS tail)"}
+        if families is not None:
+            dom = max((k for k in families if k != "other"), key=lambda k: families[k]["ms"])
+            line["roofline_by_family"] = dict(families, time_dominant=dom,
+                                              note="one untimed step with HIP events around every launch; `roofline` above is the fc1 family inside the timed region")
         if not args.no_roofline:
             line["act_l2_kernel"] = act_l2_figure(eng, args.batch, tokens, d_int, dev)
         if world == 1 and not args.no_api and args.config == 1 and args.precision == "bf16":

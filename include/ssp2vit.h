@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SSP2_ABI_VERSION 2
+#define SSP2_ABI_VERSION 3
 
 enum {
   SSP2_OK = 0,
@@ -79,6 +79,18 @@ int ssp2_set_stream(ssp2_handle h, void* hip_stream);
  * more than the device has: all CUs).  Two handles on two streams with half the CUs each run side by side instead of
  * taking turns — the point of bench.py --two-streams. */
 int ssp2_set_cu_limit(ssp2_handle h, int n_cu);
+/* Run-time switches of a handle (kernel routing and launch order; NONE of them changes a result bit — the GPU suite flips
+ * each one and compares).  Defaults come from the environment variable named beside each, read once in ssp2_create.
+ *   SSP2_OPT_ZIGZAG         1  SSP2_ZIGZAG          large launches walk their row panels opposite to the previous launch
+ *   SSP2_OPT_ATTN_PERSIST   1  SSP2_ATTN_PERSIST    d_h = 64 / 80 attention on the persistent producer / consumer kernel
+ *   SSP2_OPT_LN_FUSION      0  SSP2_LN_FUSION       LayerNorm inside the residual GEMM: 0 off, 1 where a cost model says so, 2 always
+ *   SSP2_OPT_BIG_TILES      1  SSP2_NO_BIG_TILES    launches with >= 4096 rows on the persistent 256 x 256 GEMM
+ *   SSP2_OPT_FC1_BIG_TILES  1  SSP2_FC1_SMALL_TILES fc1 of such launches too
+ *   SSP2_OPT_GROUP256       0  SSP2_GROUP256        tile order of the 256 x 256 GEMM: 0 = N fastest, 100 * GM + GN = column groups */
+enum { SSP2_OPT_ZIGZAG = 0, SSP2_OPT_ATTN_PERSIST, SSP2_OPT_LN_FUSION, SSP2_OPT_BIG_TILES, SSP2_OPT_FC1_BIG_TILES, SSP2_OPT_GROUP256,
+       SSP2_OPT_COUNT };
+int ssp2_set_option(ssp2_handle h, int option, int value);
+int ssp2_get_option(ssp2_handle h, int option);                             /* >= 0, or SSP2_EINVAL */
 
 /* fp32 HOST data in nn.Linear/Conv2d layout ([out,in], conv [dim,3,p,p]); matrices are rounded to bf16
  * (RNE) exactly as torch.autocast casts them, biases are rounded to bf16 and kept as fp32 values, LayerNorm
@@ -195,7 +207,10 @@ int ssp2_preproc_destroy(ssp2_preproc_handle p);
 enum { SSP2_K_GEMM_FC1 = 0, SSP2_K_GEMM_FC2, SSP2_K_GEMM_QKV, SSP2_K_GEMM_PROJ, SSP2_K_GEMM_PATCH,
        SSP2_K_GEMM_HEAD, SSP2_K_ATTN, SSP2_K_LN, SSP2_K_SCORE_FINISH, SSP2_K_ACT_L2, SSP2_K_OTHER,
        SSP2_K_COUNT };
-int ssp2_profile_begin(ssp2_handle h, int klass);                       /* start recording event pairs */
+int ssp2_profile_begin(ssp2_handle h, int klass);                       /* start recording event pairs; SSP2_K_COUNT = every class */
+/* totals of one class since ssp2_profile_begin: device time, launches, algorithmic flops (GEMMs 2*M*N*K, attention 4*N*N*d_h per
+ * head and image) and algorithmic HBM bytes (LayerNorm, attention).  Synchronises the stream; the recording stays on. */
+int ssp2_profile_query(ssp2_handle h, int klass, double* total_ms, int64_t* launches, double* flops, double* bytes);
 /* synchronises the stream; gemm_flops = sum of the algorithmic 2*M*N*K of the recorded launches (GEMM classes) */
 int ssp2_profile_end(ssp2_handle h, double* total_ms, int64_t* launches, double* gemm_flops);
 

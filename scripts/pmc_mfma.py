@@ -42,6 +42,6 @@ for k, c in per.items():
 rows.sort(key=lambda r: -r["total_ms"])
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2ssp-x-vit_amd"))
 from ssp2vit import _lib   # noqa: E402  (bench.py only trusts a summary recorded at the running library's source hash)
-print(json.dumps({"lib_source_hash": _lib._source_hash(), "command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline",
+print(json.dumps({"lib_source_hash": _lib._source_hash(), "model": os.environ.get("PMC_MODEL", "vit_base_patch16_224"), "precision": os.environ.get("PMC_PRECISION", "bf16"), "command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline",
                   "note": "mfma_busy_per_ns_per_simd x (1 / 2.4) = fraction of the 2.4 GHz peak rate; mfma_util_of_cycles is relative to the cycles the part actually ran",
                   "kernels": rows[:12]}, indent=1))

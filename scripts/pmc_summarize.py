@@ -31,6 +31,6 @@ n = sum(r["launches"] for r in fc1)
 avg = sum(r["launches"] * r["hbm_bytes_per_launch"] for r in fc1) / max(1, n)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2ssp-x-vit_amd"))
 from ssp2vit import _lib   # noqa: E402  (bench.py only trusts a summary recorded at the running library's source hash)
-print(json.dumps({"lib_source_hash": _lib._source_hash(), "unit": "bytes per launch; FETCH_SIZE doubled (gfx950), KiB->B; Infinity-Cache hits count as traffic",
+print(json.dumps({"lib_source_hash": _lib._source_hash(), "model": os.environ.get("PMC_MODEL", "vit_base_patch16_224"), "precision": os.environ.get("PMC_PRECISION", "bf16"), "unit": "bytes per launch; FETCH_SIZE doubled (gfx950), KiB->B; Infinity-Cache hits count as traffic",
                   "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 1 (two passes)",
                   "fc1_family": {"launches": n, "avg_hbm_bytes_per_launch": round(avg)}, "kernels": rows[:14]}, indent=1))

@@ -399,7 +399,6 @@ def test_persistent_attention_is_bit_identical_to_the_one_item_kernel(gpu, cfg, 
         w["pos"] = w["pos"][:, :ntok, :].contiguous()
     eng = VitEngine(w, max_images=192)
     g = torch.Generator().manual_seed(5)
-    old = os.environ.get("SSP2_ATTN_PERSIST")
     try:
         for n, group in ((1, 0), (43, 0), (97, 0), (192, 0), (192, 64), (150, 64)):
             px = torch.randn(n, 3, img, img, generator=g).to(gpu)
@@ -412,7 +411,7 @@ def test_persistent_attention_is_bit_identical_to_the_one_item_kernel(gpu, cfg, 
             else:
                 valid = torch.arange(n * ntok, device=gpu)
             for flag in ("1", "0"):
-                os.environ["SSP2_ATTN_PERSIST"] = flag
+                eng.set_option("attn_persist", int(flag))
                 x = eng.embed(px, group=group)
                 sc = eng.layers(x, n, score_site="pre_gelu", score_group=group) if group else eng.layers(x, n)
                 torch.cuda.synchronize()
@@ -423,10 +422,7 @@ def test_persistent_attention_is_bit_identical_to_the_one_item_kernel(gpu, cfg, 
             if group:
                 assert torch.equal(scs[0], scs[1])
     finally:
-        if old is None:
-            os.environ.pop("SSP2_ATTN_PERSIST", None)
-        else:
-            os.environ["SSP2_ATTN_PERSIST"] = old
+        eng.close()
 
 
 @pytest.mark.parametrize("cfg,layout", [("vit_huge_patch14_224_d2", "timm"), ("vit_large_patch16_224_d2", "hf"),
@@ -1236,7 +1232,7 @@ def test_fp8_engine_tracks_the_bf16_engine_within_the_e4m3_tolerance(gpu, cfg):
 @pytest.mark.parametrize("cfg,precision", [("vit_base_patch16_224_d3", "bf16"), ("vit_large_patch16_224_d2", "bf16"),
                                            ("vit_huge_patch14_224_d2", "bf16"), ("vit_base_patch16_224_d3", "fp8")])
 def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_bits(gpu, cfg, precision, monkeypatch):
-    """SSP2_LN_FUSION (opt-in, csrc/engine.hip ln_fusable): the attention out-projection and fc2 of a launch with >= 4096
+    """SSP2_OPT_LN_FUSION (opt-in, csrc/engine.hip ln_fusable; ssp2_set_option): the attention out-projection and fc2 of a launch with >= 4096
     rows normalise the row panels they finish inside the GEMM kernel (gemm256.hip.h, LNV = dim / 256 = 3, 4, 5; one workgroup
     per 256-row panel) instead of launching layernorm_bf16_kernel.  Both call ONE row routine (ln_row_finish), so logits,
     and stage-1 scores must be the same bits — with the attention of a middle block skipped (fc2 then hands
@@ -1257,9 +1253,10 @@ def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_
         for site in ("pre_gelu", "post_gelu"):
             out.append(eng.forward_scores(px, site)[0].cpu())
         return out
-    monkeypatch.delenv("SSP2_LN_FUSION", raising=False)
+    eng.set_option("ln_fusion", 0)
     plain = run()
-    monkeypatch.setenv("SSP2_LN_FUSION", "2")
+    eng.set_option("ln_fusion", 2)
+    assert eng.get_option("ln_fusion") == 2
     fused = run()
     for a, b in zip(plain, fused):
         if torch.is_tensor(a):
@@ -1267,7 +1264,7 @@ def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_
             assert bool(torch.isfinite(a).all())
         else:
             assert a == b
-    monkeypatch.setenv("SSP2_LN_FUSION", "1")                           # the cost model's choice: same bits again
+    eng.set_option("ln_fusion", 1)                                      # the cost model's choice: same bits again
     for a, b in zip(plain, run()):
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
 
@@ -1275,7 +1272,7 @@ def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_
 def test_zigzag_launch_order_does_not_change_a_bit(gpu, monkeypatch):
     """csrc/engine.hip next_dir: every large launch (persistent GEMM, LayerNorm, persistent attention) walks its row panels
     opposite to the previous one, so that it starts on what its producer wrote last (Infinity Cache).  The order never enters
-    a result: logits, both score sites and a search's counts with SSP2_ZIGZAG=0 (every launch ascending) are the same bits;
+    a result: logits, both score sites and a search's counts with SSP2_OPT_ZIGZAG = 0 (every launch ascending) are the same bits;
     two consecutive default runs (which start in opposite directions) too."""
     from ssp2vit import core
     from ssp2vit.engine import VitEngine
@@ -1291,10 +1288,10 @@ def test_zigzag_launch_order_does_not_change_a_bit(gpu, monkeypatch):
         out += [eng.forward_scores(px, s)[0].cpu() for s in ("pre_gelu", "post_gelu")]
         base, cand, total = core.depth_search_counts(eng, loader, 3, batch_limit=None, chunk_images=40)
         return out, (base, list(cand), total)
-    monkeypatch.delenv("SSP2_ZIGZAG", raising=False)
+    eng.set_option("zigzag", 1)
     a, ca = run()
     b, cb = run()
-    monkeypatch.setenv("SSP2_ZIGZAG", "0")
+    eng.set_option("zigzag", 0)
     c, cc = run()
     for x, y, z in zip(a, b, c):
         assert torch.equal(x, y) and torch.equal(x, z)

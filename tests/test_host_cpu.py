@@ -299,7 +299,22 @@ def test_bench_only_trusts_pmc_summaries_of_the_running_source(tmp_path, monkeyp
     assert bench.pmc_traffic() == (123456789, {"source": "r09_b_pmc_traffic.json"})
     (prof / "r09_b_pmc_mfma.json").write_text(js.dumps({"lib_source_hash": _lib._source_hash(), "kernels": [
         {"kernel": "void gemm256_bf16_kernel<2, 0, 0>", "mfma_util_of_cycles": 0.5, "shader_clock_ghz": 1.9}]}))
-    assert bench.pmc_mfma() == {"mfma_busy_frac_of_cycles": 0.5, "shader_clock_ghz": 1.9, "source": "r09_b_pmc_mfma.json"}
+    assert bench.pmc_mfma() == {"mfma_busy_frac_of_cycles": 0.5, "shader_clock_ghz": 1.9, "source": "r09_b_pmc_mfma.json",
+                                "model": "vit_base_patch16_224", "precision": "bf16"}
+    # ... and only summaries taken on THIS model and precision: ViT-B/16's busy fraction is no evidence for a ViT-H/14 fp8 line
+    assert bench.pmc_mfma("vit_huge_patch14_224", "fp8") is None and bench.pmc_traffic("vit_huge_patch14_224", "bf16") == (None, None)
+    (prof / "r09_c_pmc_mfma_h14_fp8.json").write_text(js.dumps({"lib_source_hash": _lib._source_hash(), "model": "vit_huge_patch14_224",
+        "precision": "fp8", "kernels": [{"kernel": "void gemm256_bf16_kernel<2, 0, true>", "mfma_util_of_cycles": 0.33, "shader_clock_ghz": 1.7}]}))
+    assert bench.pmc_mfma("vit_huge_patch14_224", "fp8")["mfma_busy_frac_of_cycles"] == 0.33
+    assert bench.pmc_mfma()["mfma_busy_frac_of_cycles"] == 0.5                  # the B/16 line does not pick the H/14 file up
+    fam = bench.roofline_by_family({"gemm_fc1": {"ms": 30.0, "launches": 40, "flops": 30e12, "bytes": 0.0},
+                                    "gemm_fc2": {"ms": 20.0, "launches": 40, "flops": 18e12, "bytes": 0.0},
+                                    "gemm_proj": {"ms": 10.0, "launches": 40, "flops": 6e12, "bytes": 0.0},
+                                    "ln": {"ms": 10.0, "launches": 80, "flops": 0.0, "bytes": 50e9},
+                                    "attn": {"ms": 5.0, "launches": 40, "flops": 1e12, "bytes": 10e9}}, "bf16")
+    assert fam["fc1"]["achieved"] == 1000.0 and fam["fc1"]["frac"] == 0.4 and fam["resid"]["achieved"] == 800.0
+    assert fam["layernorm"]["bound"] == "hbm" and fam["layernorm"]["achieved"] == 5000.0 and fam["attention"]["achieved"] == 2000.0
+    assert abs(sum(f["share_of_kernel_time"] for f in fam.values()) - 1.0) < 1e-3 and "qkv" not in fam
     # the summary writers record the hash
     for script in ("pmc_summarize.py", "pmc_mfma.py", "pmc_act_l2.sh"):
         assert "lib_source_hash" in open(os.path.join(root, "scripts", script)).read()
@@ -433,3 +448,98 @@ def test_pruned_model_export_hf_directory_and_timm_state_dict(tmp_path):
         sd = load_file(os.path.join(d, "model.safetensors"))           # (transformers 5 writes the checkpoint with the legacy key names)
         key = "vit.layers.0.mlp.fc1.weight" if "vit.layers.0.mlp.fc1.weight" in sd else "vit.encoder.layer.0.intermediate.dense.weight"
         assert sd[key].shape == (88, 64)
+
+
+# ------------------------------------------------------------------------------------------ bench.py --gpus N self-launch
+def test_bench_launcher_plan_argv_and_env():
+    import bench
+    env = {"PATH": "/usr/bin", "HOME": "/root"}
+    assert bench.launcher_plan(["--steps", "3"], env) is None                       # N = 1: this process is the job
+    assert bench.launcher_plan(["--gpus", "1"], env) is None
+    assert bench.launcher_plan(["--gpus", "8"], dict(env, RANK="0", WORLD_SIZE="8")) is None      # already a rank (driver's torchrun)
+    plan = bench.launcher_plan(["--gpus", "8", "--steps", "20", "--warmup", "5"], env)
+    cmd = plan["cmd"]
+    assert plan["n"] == 8 and cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]        # the ranks see the caller's own flags
+    assert plan["env"]["MASTER_ADDR"] == "127.0.0.1" and plan["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "RANK" not in plan["env"] and plan["env"]["PATH"] == "/usr/bin"
+    assert bench.launcher_plan(["--gpus=4"], dict(env, MASTER_PORT="29555"))["cmd"].count("29555") == 1
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("sys.exit(run_launcher(_plan))") < src.index("\nimport torch")  # the parent leaves before torch is imported
+
+
+def test_bench_self_launch_two_ranks_relays_rank0_line_and_failures():
+    """`python bench.py --gpus 2` without a torch.distributed environment starts two child ranks (gloo self-test mode: no
+    GPU), relays rank 0's JSON line and exits 0; the PARENT runs with `torch` poisoned in sys.modules, so it provably
+    never imports it (hence never initialises HIP); a failing rank makes the whole command fail."""
+    import subprocess
+    code = ("import sys, runpy; sys.modules['torch'] = None; sys.argv = ['bench.py', '--gpus', '2', '--selftest-launcher']; "
+            f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines == [{"metric": "launcher_selftest", "n_gpus": 2, "cuda_initialised": False}]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launcher"], capture_output=True,
+                         text=True, timeout=300, env=dict(env, SSP2_SELFTEST_FAIL_RANK="1"))
+    assert bad.returncode != 0
+
+
+# ------------------------------------------------------------------------------------------ CLI --weights / --gpus
+def test_local_checkpoints_load_in_all_three_key_layouts(tmp_path):
+    """weights.load_checkpoint (CLI --weights; reference auto_2ssp.py:636-667 loads with from_pretrained / timm): an HF-style
+    directory written by ssp2vit.export, a bare .safetensors and a .pth state dict, in the timm, transformers<5 and
+    transformers>=5 key layouts, give back the flat dictionary `from_module` reads off the live module — bit for bit —
+    incl. a width-pruned model and one whose block 1 lost its attention (pruning_meta.json)."""
+    from oracle.vit_modules import build_from_flat
+    from safetensors.torch import save_file
+    from ssp2vit import export, vit_pruning as vp, weights as W
+    w = W.synthetic_weights("vit_test_patch16_32", classes=10, seed=3, std=0.2, bias_std=0.1)
+    def same(a, b):
+        keys = [k for k in a if torch.is_tensor(a[k])]
+        assert keys and all(torch.equal(a[k].reshape(-1).float(), b[k].reshape(-1).float()) for k in keys), \
+            [k for k in keys if not torch.equal(a[k].reshape(-1).float(), b[k].reshape(-1).float())][:3]
+        assert all(a[k] == b[k] for k in ("img", "patch", "dim", "heads", "depth", "classes"))
+    for layout in ("timm", "hf"):
+        m = build_from_flat(w, layout)
+        vp.prune_vit_mlp_width(m, n_to_prune_per_block=[40, 0, 17, 3], min_remaining=16, strategy="l1")
+        vp._apply_bypass(m, 1)
+        want = W.from_module(m)
+        d = export.save_pretrained_dir(m, str(tmp_path / f"dir_{layout}"))
+        got = W.load_checkpoint(d, heads=4)
+        same(want, got)
+        assert got["layout"] == layout and got.get("attn_absent.1") and [got[f"fc1_w.{i}"].shape[0] for i in range(4)] == [88, 128, 111, 125]
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        save_file(sd, str(tmp_path / f"{layout}.safetensors"))
+        torch.save(sd, str(tmp_path / f"{layout}.pth"))
+        for f in (f"{layout}.safetensors", f"{layout}.pth"):      # bare files: no pruning_meta -> the absent block is seen from its missing keys
+            same(want, W.load_checkpoint(str(tmp_path / f), heads=4))
+    with pytest.raises(AttributeError):
+        W.load_checkpoint(str(tmp_path / "timm.pth"))               # hidden size 64: no published geometry, heads must be given
+    with pytest.raises(AttributeError):
+        W.from_state_dict({"foo.weight": torch.zeros(2, 2)})
+    # transformers >= 5 layout from the installed library's own module (random init, no download)
+    tr = pytest.importorskip("transformers")
+    cfg = tr.ViTConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, image_size=32, patch_size=16,
+                       num_labels=10)
+    hf = tr.ViTForImageClassification(cfg).eval()
+    if W.detect_layout(hf) == "hf5":
+        got = W.from_state_dict(hf.state_dict(), cfg.to_dict())
+        same(W.from_module(hf), got)
+        assert got["layout"] == "hf5" and got["heads"] == 4 and got["eps"] == cfg.layer_norm_eps
+
+
+def test_cli_launcher_plan_and_flags():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("auto_2ssp_cli", os.path.join(PKG, "auto_2ssp.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    assert cli.launcher_plan(["--target", "0.375"], {}) is None and cli.launcher_plan(["--gpus", "4"], {"RANK": "1"}) is None
+    plan = cli.launcher_plan(["--gpus", "4", "--target", "0.375", "--weights", "/x/m.safetensors"], {"PATH": "/bin"})
+    assert plan["n"] == 4 and "--nproc-per-node=4" in plan["cmd"] and plan["cmd"][-6:] == ["--gpus", "4", "--target", "0.375", "--weights", "/x/m.safetensors"]
+    assert plan["env"]["MASTER_ADDR"] == "127.0.0.1"
+    a = cli.build_argparser().parse_args(["--weights", "ck", "--heads", "12", "--gpus", "2", "--target", "0.5"])
+    assert (a.weights, a.heads, a.gpus, a.target) == ("ck", 12, 2, 0.5)
