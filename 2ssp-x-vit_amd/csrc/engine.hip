@@ -18,6 +18,7 @@
 #include "attn.hip.h"
 #include "gemm256.hip.h"
 #include "misc.hip.h"
+#include "patch.hip.h"
 #include "preproc.hip.h"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -386,6 +387,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
     e->opt[SSP2_OPT_BIG_TILES] = getenv("SSP2_NO_BIG_TILES") ? 0 : 1;
     e->opt[SSP2_OPT_FC1_BIG_TILES] = getenv("SSP2_FC1_SMALL_TILES") ? 0 : 1;
     e->opt[SSP2_OPT_GROUP256] = env_int("SSP2_GROUP256", 0);
+    e->opt[SSP2_OPT_PATCH_LDS] = env_int("SSP2_PATCH_LDS", 1);
   }
   e->d_int.assign(d.d_int, d.d_int + d.depth);
   e->d.d_int = e->d_int.data();
@@ -424,7 +426,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
   e->rows_cap = (long)d.max_images * e->tokens + 16 * 256;     // slack: up to 16 padded slabs per call
   const size_t M = (size_t)e->rows_cap;
   const size_t tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
-  TRY(dalloc(e, &e->a_pe, (size_t)d.max_images * e->patches * e->kpe_pad, true));
+  // (a_pe, the im2col image of the old patch-embed path, is allocated only if SSP2_OPT_PATCH_LDS is switched off: see ssp2_embed)
   TRY(dalloc(e, &e->hbuf, M * d.dim, true));
   TRY(dalloc(e, &e->qkvbuf, M * 3 * d.dim, true));
   TRY(dalloc(e, &e->obuf, M * d.dim, true));
@@ -634,12 +636,39 @@ int ssp2_embed(ssp2_handle e, const float* pixels_dev, int n, float* x_dev, int 
     HIPCHK(hipMemsetAsync(x_dev, 0, (size_t)total_rows(rm, n) * D * 4, e->stream));
   {
     ProfScope ps(e, SSP2_K_OTHER);
+    hipLaunchKernelGGL(cls_row_kernel, dim3((n * D + 255) / 256), dim3(256), 0, e->stream, x_dev, e->cls, e->pos, n, rm, D);
+    HIPCHK(hipGetLastError());
+  }
+  if (e->opt[SSP2_OPT_PATCH_LDS]) {
+    // default: the patch tiles go pixels -> registers (bf16 rounding) -> LDS inside the GEMM kernel (patch.hip.h); the
+    // im2col image (154 MB per 512 ViT-B/16 images, written and read back) does not exist
+    PatchArgs a{};
+    a.px = pixels_dev; a.W = e->patch.w; a.ldw = e->patch.ld; a.bias = e->patch.b; a.pos = e->pos; a.x = x_dev; a.ldx = D;
+    a.n = n; a.img = e->d.img; a.p = e->d.patch; a.side = e->side; a.K = e->kpe; a.Kpad = e->kpe_pad; a.N = D;
+    a.tiles_n = e->patch.rows_pad / GEMM_BN; a.rm = rm;
+    const int tiles_m = (n * e->patches + GEMM_BM - 1) / GEMM_BM;
+    static bool attr_done[kMaxDevices] = {};
+    if (!attr_done[e->dev]) {
+      HIPCHK(hipFuncSetAttribute((const void*)patch_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PATCH_LDS_BYTES));
+      attr_done[e->dev] = true;
+    }
+    ProfScope ps(e, SSP2_K_GEMM_PATCH, 2.0 * n * e->patches * (double)D * e->kpe_pad);
+    hipLaunchKernelGGL(patch_embed_kernel, dim3(tiles_m * a.tiles_n), dim3(256), PATCH_LDS_BYTES, e->stream, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  // SSP2_OPT_PATCH_LDS = 0 (the round-1/2 path, kept for the bit-identity test): im2col image in HBM + gemm_bf16_kernel<EPI_PATCH>
+  if (!e->a_pe) {
+    int rc2;
+    if ((rc2 = dalloc(e, &e->a_pe, (size_t)e->d.max_images * e->patches * e->kpe_pad, true))) return rc2;
+  }
+  {
+    ProfScope ps(e, SSP2_K_OTHER);
     const long total = (long)n * e->patches * (e->kpe_pad / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(im2col_patch_kernel, dim3(blocks), dim3(256), 0, e->stream, pixels_dev, e->a_pe, n, e->d.img,
                        e->d.patch, e->side, e->kpe, e->kpe_pad);
-    hipLaunchKernelGGL(cls_row_kernel, dim3((n * D + 255) / 256), dim3(256), 0, e->stream, x_dev, e->cls, e->pos, n, rm, D);
     HIPCHK(hipGetLastError());
   }
   GemmArgs g{};

@@ -1318,3 +1318,48 @@ def test_scores_only_forward_stops_behind_the_last_hooked_activation_with_the_sa
         eng.layers(x2, 40, 0, eng.depth, None, site, "fp32", None, 8, scores_only=True)
         assert not torch.equal(x, x2)                    # the last fc2 did not run
     assert eng.lib.ssp2_layers(eng.h, x.data_ptr(), 40, 0, eng.depth, None, 0x10, 0, 8, None, eng.score_ld) != 0   # the flag without a site
+
+
+def test_patch_embed_with_lds_staged_patch_tiles_gives_the_im2col_paths_bits(gpu):
+    """north_star: "patch-embed ... on MFMA with LDS-staged patch tiles".  csrc/patch.hip.h gathers a workgroup's patch tile
+    from the fp32 NCHW pixels into registers, rounds it to bf16 and writes it into LDS in the swizzled image the LDS-DMA
+    path produces; the round-1/2 path (im2col image in HBM + gemm_bf16_kernel<EPI_PATCH>, SSP2_OPT_PATCH_LDS = 0) is kept
+    for this test.  Same K order, same MFMA order, same epilogue => the residual stream after the embedding must be the same
+    bits: patch 16 (16-byte pixel runs: ViT-B/16 width and the 32-pixel smoke geometry), patch 14 (ViT-H/14: K = 588, not
+    a multiple of 64, element-wise gather), contiguous and slab row layouts, image counts that leave a ragged last row tile.
+    And against a plain fp32 PyTorch statement of the convolution on the bf16-rounded operands (one bf16 rounding + fp32
+    summation order)."""
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    g = torch.Generator().manual_seed(17)
+    for cfg, n_list in (("vit_base_patch16_224_d3", (1, 5, 40)), ("vit_huge_patch14_224_d2", (3, 17)), ("vit_test_patch16_32", (1, 7, 64))):
+        w = synthetic_weights(cfg, classes=10, seed=4, std=0.05, eps=1e-6, bias_std=0.05)
+        eng = VitEngine(w, max_images=64)
+        img, p, dim = int(w["img"]), int(w["patch"]), int(w["dim"])
+        for n in n_list:
+            px = torch.randn(n, 3, img, img, generator=g).to(gpu)
+            for group in (0, 4):
+                if group and group >= n:
+                    continue
+                eng.set_option("patch_lds", 1)
+                a = eng.embed(px, group=group).clone()
+                eng.set_option("patch_lds", 0)
+                b = eng.embed(px, group=group).clone()
+                torch.cuda.synchronize()
+                if group:
+                    mpad, ntok = eng.rows(group, group), eng.tokens
+                    valid = torch.cat([torch.arange(s0 * mpad, s0 * mpad + min(group, n - s0 * group) * ntok)
+                                       for s0 in range((n + group - 1) // group)]).to(gpu)
+                    a, b = a[valid], b[valid]
+                assert torch.equal(a, b), (cfg, n, group)
+                assert bool(torch.isfinite(a).all())
+            if n <= 5:       # vs torch: conv on bf16-rounded pixels / weights in fp32, + bias(bf16) -> bf16 -> + pos
+                eng.set_option("patch_lds", 1)
+                x = eng.embed(px).view(n, eng.tokens, dim)
+                ref = torch.nn.functional.conv2d(px.to(torch.bfloat16).float(), w["patch_w"].to(gpu).to(torch.bfloat16).float(), None, stride=p)
+                ref = ref.flatten(2).transpose(1, 2) + w["patch_b"].to(gpu).to(torch.bfloat16).float()
+                ref = ref.to(torch.bfloat16).float() + w["pos"].to(gpu)[:, 1:, :]
+                err = (x[:, 1:, :] - ref).abs()
+                assert float(err.max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-6, (cfg, n, float(err.max()))
+                assert torch.equal(x[:, 0, :], (w["cls"].to(gpu) + w["pos"].to(gpu)[:, :1, :]).view(1, dim).expand(n, dim))
+        eng.close()
