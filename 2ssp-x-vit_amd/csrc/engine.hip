@@ -632,8 +632,12 @@ int ssp2_embed(ssp2_handle e, const float* pixels_dev, int n, float* x_dev, int 
   if (!pixels_dev || !x_dev) return fail(SSP2_EINVAL, "null device pointer");
   if (!(e->patch.w_set && e->patch.b_set && e->misc_set[0] && e->misc_set[1])) return fail(SSP2_ESTATE, "patch/cls/pos weights not loaded");
   const int D = e->d.dim;
-  if (rm.group > 0)   // pad rows between slabs must hold finite values: they flow through LN / GEMMs (never scored)
-    HIPCHK(hipMemsetAsync(x_dev, 0, (size_t)total_rows(rm, n) * D * 4, e->stream));
+  if (rm.group > 0) {   // pad rows between slabs must hold finite values: they flow through LN / GEMMs (never scored).  Only THEY are
+    // zeroed (one strided fill: 4.7 MB for eight 64-image ViT-B/16 slabs; round 2 cleared all 310 MB of x per stage-1 launch)
+    const int n_slabs = (n + rm.group - 1) / rm.group, pad_rows = rm.mpad - rm.group * rm.tokens;
+    if (n_slabs > 1 && pad_rows > 0)
+      HIPCHK(hipMemset2DAsync(x_dev + (size_t)rm.group * rm.tokens * D, (size_t)rm.mpad * D * 4, 0, (size_t)pad_rows * D * 4, (size_t)(n_slabs - 1), e->stream));
+  }
   {
     ProfScope ps(e, SSP2_K_OTHER);
     hipLaunchKernelGGL(cls_row_kernel, dim3((n * D + 255) / 256), dim3(256), 0, e->stream, x_dev, e->cls, e->pos, n, rm, D);
@@ -680,6 +684,11 @@ int ssp2_embed(ssp2_handle e, const float* pixels_dev, int n, float* x_dev, int 
 
 int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const uint8_t* attn_skip, int score_site,
                 int score_chain, int score_group, float* batch_scores, int score_ld) {
+  return ssp2_layers_from(e, nullptr, x, n, l_begin, l_end, attn_skip, score_site, score_chain, score_group, batch_scores, score_ld);
+}
+
+int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_begin, int l_end, const uint8_t* attn_skip, int score_site,
+                     int score_chain, int score_group, float* batch_scores, int score_ld) {
   int rc;
   if ((rc = check_n(e, n, score_group))) return rc;
   if (!x) return fail(SSP2_EINVAL, "null x");
@@ -700,6 +709,10 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
   const bool f8 = e->fp8 && M >= kBigTileMinRows;
   const bool f8_fc1 = f8 && fused_ok_for_fp8(score_site, e->tokens);
   bool h_ready = false;          // hbuf / hbuf8 already holds the LayerNorm the next projection reads (written by a residual GEMM)
+  // x_in: the residual stream ENTERING block l_begin is read from there (LayerNorm input and the first residual add), everything
+  // from the first residual add on lives in x — out of place for one residual epilogue, no copy of the stream
+  const float* xsrc = (x_in && x_in != x) ? x_in : x;
+  if (xsrc != x && e->opt[SSP2_OPT_LN_FUSION]) return fail(SSP2_EINVAL, "ssp2_layers_from: out-of-place input with the fused LayerNorm is not supported");
   auto set_ln = [&](GemmArgs& a, const float* gm, const float* bt, bool to_fp8) {
     a.ln_g = gm; a.ln_b = bt; a.ln_eps = e->d.ln_eps;
     if (to_fp8) { a.ln_out8 = e->hbuf8; a.ln_ld = e->ld8_dim; } else { a.ln_out = e->hbuf; a.ln_ld = D; }
@@ -715,11 +728,11 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
       GemmArgs q{};
       q.bias = L.qkv.b; q.M = M; q.N = 3 * D; q.tiles_n = L.qkv.rows_pad / GEMM_BN; q.out = e->qkvbuf; q.ldo = 3 * D;
       if (f8) {
-        if (!h_ready && (rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
+        if (!h_ready && (rc = launch_ln(e, xsrc, D, L.ln1_g, L.ln1_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
         q.A = (const bf16*)e->hbuf8; q.lda = e->ld8_dim; q.W = (const bf16*)L.qkv.w8; q.ldw = L.qkv.ld8; q.K = e->ld8_dim; q.wscale = L.qkv.wscale;
         if ((rc = launch_gemm256<EPI_BF16, 0, true>(e, q, SSP2_K_GEMM_QKV))) return rc;
       } else {
-        if (!h_ready && (rc = launch_ln(e, x, D, L.ln1_g, L.ln1_b, e->hbuf, D, M, D))) return rc;
+        if (!h_ready && (rc = launch_ln(e, xsrc, D, L.ln1_g, L.ln1_b, e->hbuf, D, M, D))) return rc;
         q.A = e->hbuf; q.lda = D; q.W = L.qkv.w; q.ldw = L.qkv.ld; q.K = D;
         if ((rc = launch_gemm<EPI_BF16>(e, q, SSP2_K_GEMM_QKV))) return rc;
       }
@@ -727,22 +740,23 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
       if ((rc = launch_attn(e, n, rm))) return rc;
       GemmArgs p{};
       p.A = e->obuf; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.bias = L.proj.b;
-      p.M = M; p.N = D; p.K = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = x; p.ldx = D;
+      p.M = M; p.N = D; p.K = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = x; p.ldx = D; p.xin = xsrc;
       if (const int lnv = ln_fusable(e, M, D, false)) {          // + LN2 of this layer: fc1's operand
         set_ln(p, L.ln2_g, L.ln2_b, f8_fc1);
         if ((rc = launch_resid_ln<false>(e, p, lnv, SSP2_K_GEMM_PROJ))) return rc;
         h_ready = true;
       } else if ((rc = launch_gemm<EPI_RESID>(e, p, SSP2_K_GEMM_PROJ))) return rc;
+      xsrc = x;
     }
     const int ld8_int = ceil_to(L.ld_int, 128);
     GemmArgs f{};
     f.bias = L.fc1.b; f.M = M; f.tiles_n = L.fc1.rows_pad / GEMM_BN;
     if (f8_fc1) {
-      if (!h_ready && (rc = launch_ln(e, x, D, L.ln2_g, L.ln2_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
+      if (!h_ready && (rc = launch_ln(e, xsrc, D, L.ln2_g, L.ln2_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
       f.A = (const bf16*)e->hbuf8; f.lda = e->ld8_dim; f.W = (const bf16*)L.fc1.w8; f.ldw = L.fc1.ld8; f.K = e->ld8_dim; f.wscale = L.fc1.wscale;
       f.N = ld8_int; f.out = (bf16*)e->act8; f.ldo = ld8_int;      // e4m3 bytes out; the pad columns up to 128 are written (zeros)
     } else {
-      if (!h_ready && (rc = launch_ln(e, x, D, L.ln2_g, L.ln2_b, e->hbuf, D, M, D))) return rc;
+      if (!h_ready && (rc = launch_ln(e, xsrc, D, L.ln2_g, L.ln2_b, e->hbuf, D, M, D))) return rc;
       f.A = e->hbuf; f.lda = D; f.W = L.fc1.w; f.ldw = L.fc1.ld; f.K = D;
       f.N = L.ld_int; f.out = e->actbuf; f.ldo = L.ld_int;
     }
@@ -781,7 +795,7 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
     }
     if (scores_only && l + 1 == l_end) break;            // nothing reads x behind the last hooked activation
     GemmArgs o{};
-    o.bias = L.fc2.b; o.M = M; o.N = D; o.tiles_n = L.fc2.rows_pad / GEMM_BN; o.x = x; o.ldx = D;
+    o.bias = L.fc2.b; o.M = M; o.N = D; o.tiles_n = L.fc2.rows_pad / GEMM_BN; o.x = x; o.ldx = D; o.xin = xsrc;
     // + the LayerNorm the NEXT layer of this call starts with: LN1 of layer l + 1, or its LN2 when its attention is skipped
     int lnv = 0;
     if (l + 1 < l_end) {
@@ -800,6 +814,7 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
       if ((rc = lnv ? launch_resid_ln<false>(e, o, lnv, SSP2_K_GEMM_FC2) : launch_gemm<EPI_RESID>(e, o, SSP2_K_GEMM_FC2))) return rc;
     }
     h_ready = lnv != 0;
+    xsrc = x;
   }
   return 0;
 }

@@ -44,6 +44,7 @@ struct GemmArgs {
   bf16* out; int ldo;         // EPI_BF16 / EPI_FC1
   bf16* out2;                 // EPI_FC1: optional pre-GELU copy (same ld)
   float* x; int ldx;          // EPI_RESID / EPI_PATCH / EPI_F32
+  const float* xin;           // EPI_RESID: where the residual is READ (same shape / ld as x); nullptr = x itself (in place)
   // EPI_FC1
   int score_site;             // 0 none, 1 pre-GELU, 2 post-GELU
   int tokens;                 // tokens per sample (>= GEMM_BM when score_site != 0)
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
       const int mc = m < g.M ? m : g.M - 1;
       if (EPI == EPI_RESID) {
         dst[it] = g.x + (size_t)mc * g.ldx + col0 + c;
-        xin[it] = *(const f32x4*)dst[it];
+        xin[it] = *(const f32x4*)((g.xin ? g.xin : g.x) + (size_t)mc * g.ldx + col0 + c);
       } else {
         const int img = mc / g.patches, p = mc - img * g.patches;
         const RowMap rm{g.patches + 1, g.group, g.mpad};

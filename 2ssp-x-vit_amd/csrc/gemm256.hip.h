@@ -698,6 +698,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         // offset): their loads return 0 and their stores are dropped by the hardware — edge tiles take the same
         // straight-line code, no branches, no exec masks.
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xw, 0, 0x7ffffff0, 0x00020000);   // base = the wave's window
+        // the residual may be READ from another stream of the same shape (g.xin: the search's candidate l takes block l's input
+        // from the baseline's slot and writes its own, csrc/engine.hip ssp2_layers_from): a second descriptor, 4 SGPRs
+        float* const xw_in = const_cast<float*>(g.xin ? g.xin : g.x) + (size_t)row0 * g.ldx + col0;
+        const __amdgpu_buffer_rsrc_t xr_in = __builtin_amdgcn_make_buffer_rsrc(xw_in, 0, 0x7ffffff0, 0x00020000);
         const int lane_off = (dr * g.ldx + cc * 4) * 4;              // bytes: row dr of a piece, 16-byte chunk cc
         auto xoff = [&](int a, int b, int j) -> int {                // bytes, wave-uniform
           return ((a * 32 + 8 * j) * g.ldx + b * 32) * 4;
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         for (int p = 0; p < NXB; ++p)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            xin[p][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff(p >> 1, j), xoff(p >> 1, p & 1, j), 0));
+            xin[p][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_in, voff(p >> 1, j), xoff(p >> 1, p & 1, j), 0));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0); // hoist these loads to the top and spill their destinations)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              xin[p % NXB][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff((p + NXB) >> 1, j), xoff((p + NXB) >> 1, (p + NXB) & 1, j), 0));
+              xin[p % NXB][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_in, voff((p + NXB) >> 1, j), xoff((p + NXB) >> 1, (p + NXB) & 1, j), 0));
             __builtin_amdgcn_sched_barrier(0);
           }
         }

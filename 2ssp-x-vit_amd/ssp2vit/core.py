@@ -142,9 +142,9 @@ class _Chunker:
                            None if labels is None else _to_device(labels, self.device, torch.int64)))
         self.count += int(batch["pixel_values"].size(0))
 
-    def take(self):
+    def take(self, as_list: bool = False):
         items, self.items, self.count = self.items, [], 0
-        px = items[0][1] if len(items) == 1 else torch.cat([it[1] for it in items], 0)
+        px = items[0][1] if len(items) == 1 else ([it[1] for it in items] if as_list else torch.cat([it[1] for it in items], 0))
         labels = None
         if items[0][2] is not None:
             labels = items[0][2] if len(items) == 1 else torch.cat([it[2] for it in items], 0)
@@ -180,7 +180,7 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
     ramp = []                    # capacities of the launches that follow the first (host-fed batches only, see below)
 
     def flush():
-        idxs, group, px, _ = ch.take()
+        idxs, group, px, _ = ch.take(as_list=getattr(eng, "batch_lists", False))     # VitEngine embeds each batch into its slab: no cat
         vec = eng.forward_scores(px, site, score_chain, group)      # [len(idxs), L, ld]
         for k, i in enumerate(idxs):
             local.append((i, vec[k]))
@@ -275,8 +275,23 @@ def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images, c
 
     def cut(k):
         nonlocal px_buf, lb_buf, count
-        px = px_buf[0] if len(px_buf) == 1 else torch.cat(px_buf, 0)
         lb = lb_buf[0] if len(lb_buf) == 1 else torch.cat(lb_buf, 0)
+        if getattr(eng, "batch_lists", False):
+            # the chunk's pixels stay a LIST of (views of) the loader's batches: the engine embeds each into its rows of the
+            # token matrix — no concatenated copy of the pixels (193 MB per 320-image chunk of ViT-B/16)
+            take, rest, left = [], [], k
+            for p in px_buf:
+                m = int(p.shape[0])
+                if left >= m:
+                    take.append(p); left -= m
+                elif left > 0:
+                    take.append(p[:left]); rest.append(p[left:]); left = 0
+                else:
+                    rest.append(p)
+            out = (eng, take[0] if len(take) == 1 else take, lb[:k])
+            px_buf, lb_buf, count = (rest, [lb[k:]], count - k) if k < count else ([], [], 0)
+            return out
+        px = px_buf[0] if len(px_buf) == 1 else torch.cat(px_buf, 0)
         out = (eng, px[:k], lb[:k])
         px_buf, lb_buf, count = ([px[k:]], [lb[k:]], count - k) if k < count else ([], [], 0)
         return out
@@ -328,7 +343,7 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
                                    chunk_images or DEFAULT_EVAL_CHUNK_IMAGES, sharded=sharded):
         if correct_dev is None:
             correct_dev = torch.zeros(1, dtype=torch.int64, device=eng.device)
-        n = int(px.size(0))
+        n = int(labels.size(0))
         x = eng.embed(px)
         eng.layers(x, n, 0, eng.depth - 1, attn_skip)
         eng.tail(x, n, attn_skip, labels=labels, correct=correct_dev)      # last block + head on the CLS rows
@@ -381,7 +396,7 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
     for eng, px, labels in _chunks(engine, dataloader, batch_limit, False, "attn search", rank, ws, chunk, cap_fn, sharded):
         if counts_dev is None:
             counts_dev = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
-        n = int(px.size(0))
+        n = int(labels.size(0))
         x = eng.embed(px)
         if want_lm and eng.max_images >= slots * n:
             # Layer-major search: the baseline (slot 0) and the snapshots (the k-th candidate to start in slot k) sit
@@ -398,10 +413,12 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
             for l in range(L - 1):
                 k = len(started)
                 if l in cand_set:
-                    xb[(k + 1) * rows:(k + 2) * rows].copy_(xb[:rows])              # snapshot: input of block l
+                    # candidate l: block l without its attention, started STRAIGHT from the baseline's stream (slot 0 still holds
+                    # the input of block l) into its own slot — the fc2 epilogue reads slot 0 and writes slot k + 1
+                    # (ssp2_layers_from).  Round 2 copied the 194 MB stream into the slot first: 11 copies per step.
+                    eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l], x_in=xb[:rows])
                 eng.layers(xb[:(k + 1) * rows], (k + 1) * n, l, l + 1, [l] if l in removed_set else None)
                 if l in cand_set:
-                    eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l])   # candidate l: no attention in block l
                     started.append(l)
             eng.tail(xb[:rows], n, removed, labels=labels, correct=counts_dev[L:L + 1])
             for k, c in enumerate(started):

@@ -181,7 +181,30 @@ class VitEngine:
         return torch.zeros(groups, self.depth, self.score_ld, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ the four device entry points
-    def embed(self, pixels: torch.Tensor, x: Optional[torch.Tensor] = None, group: int = 0) -> torch.Tensor:
+    batch_lists = True          # embed / forward_scores take a LIST of batches: each lands in its rows of x, nothing is concatenated
+
+    def embed(self, pixels, x: Optional[torch.Tensor] = None, group: int = 0) -> torch.Tensor:
+        if isinstance(pixels, (list, tuple)):
+            # several dataloader batches -> one token matrix, each batch embedded straight into its rows (round 2 built one
+            # pixel tensor with torch.cat first: 308 MB copied per 512-image stage-1 launch).  Slab layout (group > 0): batch
+            # b is slab b and must hold `group` images, except the last; contiguous layout: batches back to back.
+            n = sum(int(p.shape[0]) for p in pixels)
+            x = self.new_x(n, group) if x is None else x
+            if group > 0 and group < n:
+                mpad = (group * self.tokens + 255) // 256 * 256
+                pad = mpad - group * self.tokens
+                if pad:                                    # pad rows between slabs: finite values (they flow through LN / GEMMs)
+                    x[: (len(pixels) - 1) * mpad].view(len(pixels) - 1, mpad, self.dim)[:, group * self.tokens:, :].zero_()
+                for b, p in enumerate(pixels):
+                    if int(p.shape[0]) != group and b != len(pixels) - 1:
+                        raise ValueError("slab layout: every batch but the last must hold `group` images")
+                    self.embed(p, x=x[b * mpad:], group=0)
+            else:
+                row = 0
+                for p in pixels:
+                    self.embed(p, x=x[row:], group=0)
+                    row += int(p.shape[0]) * self.tokens
+            return x
         if pixels.dim() != 4 or pixels.shape[1] != 3 or pixels.shape[2] != self.img or pixels.shape[3] != self.img:
             raise ValueError(f"pixel_values must be [n,3,{self.img},{self.img}], got {tuple(pixels.shape)}")
         px = pixels.to(self.device, torch.float32, non_blocking=True).contiguous()
@@ -193,17 +216,21 @@ class VitEngine:
 
     def layers(self, x: torch.Tensor, n: int, l_begin: int = 0, l_end: Optional[int] = None,
                attn_skip: Optional[Sequence[int]] = None, score_site: str = "none", score_chain: str = "fp32",
-               batch_scores: Optional[torch.Tensor] = None, score_group: int = 0, scores_only: bool = False) -> Optional[torch.Tensor]:
+               batch_scores: Optional[torch.Tensor] = None, score_group: int = 0, scores_only: bool = False,
+               x_in: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """Returns f32 [groups, depth, score_ld] when scoring (groups = ceil(n / score_group), 1 if score_group=0).
-        `scores_only`: x is scratch afterwards — the last block stops behind its hooked activation (SSP2_SCORE_ONLY)."""
+        `scores_only`: x is scratch afterwards — the last block stops behind its hooked activation (SSP2_SCORE_ONLY).
+        `x_in`: the stream entering block l_begin is read from there and left untouched (ssp2_layers_from); x receives the result."""
         l_end = self.depth if l_end is None else l_end
         site = SCORE_SITE[score_site] | (0x10 if (scores_only and SCORE_SITE[score_site]) else 0)
         grp = n if (score_group <= 0 or score_group > n) else score_group
         if site and batch_scores is None:
             batch_scores = self.new_scores((n + grp - 1) // grp)
         self._bind_stream()
-        check(self.lib.ssp2_layers(self.h, _ptr(x), n, l_begin, l_end, self._skip_array(attn_skip), site,
-                                   SCORE_CHAIN[score_chain], int(score_group), _ptr(batch_scores if site else None), self.score_ld))
+        if x_in is not None and (x_in.shape[0] < x.shape[0] or x_in.shape[1:] != x.shape[1:] or x_in.dtype != x.dtype or not x_in.is_contiguous()):
+            raise ValueError("x_in must be a contiguous stream of the shape of x")
+        check(self.lib.ssp2_layers_from(self.h, _ptr(x_in), _ptr(x), n, l_begin, l_end, self._skip_array(attn_skip), site,
+                                        SCORE_CHAIN[score_chain], int(score_group), _ptr(batch_scores if site else None), self.score_ld))
         return batch_scores if site else None
 
     def head(self, x: torch.Tensor, n: int, labels: Optional[torch.Tensor] = None,
@@ -277,7 +304,7 @@ class VitEngine:
         """One forward over `pixels` (one or several dataloader batches of `group` images each, concatenated).
         Returns f32 [n_groups, depth, score_ld]; entry [g, l] = sum over group g's samples of the per-sample
         token-L2 of block l's FFN activation (reference hook body, src/vit_pruning.py:151-152)."""
-        n = pixels.shape[0]
+        n = sum(int(p.shape[0]) for p in pixels) if isinstance(pixels, (list, tuple)) else pixels.shape[0]
         if n > self.max_images:
             raise Ssp2Error(f"chunk of {n} images exceeds engine capacity {self.max_images}")
         x = self.embed(pixels, group=group)             # slab layout: one 256-row-aligned slab per batch

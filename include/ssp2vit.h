@@ -135,6 +135,13 @@ int ssp2_embed(ssp2_handle h, const float* pixels_dev, int n, float* x_dev, int 
  *                  score_ld >= max d_int;  score_group <= 0 means one group of n. */
 int ssp2_layers(ssp2_handle h, float* x_dev, int n, int l_begin, int l_end, const uint8_t* attn_skip,
                 int score_site, int score_chain, int score_group, float* batch_scores_dev, int score_ld);
+/* The same with the residual stream ENTERING block l_begin read from x_in_dev (same shape and row layout as x_dev, not
+ * overlapping it; NULL = x_dev): every LayerNorm in front of the first residual add and that add itself read x_in_dev, the add
+ * writes x_dev, everything after it runs in place on x_dev.  x_in_dev is left untouched.  This is how the depth search starts
+ * candidate l from the baseline's stream without copying it (reference: a deep copy of the whole model per candidate,
+ * src/vit_pruning.py:477-480). */
+int ssp2_layers_from(ssp2_handle h, const float* x_in_dev, float* x_dev, int n, int l_begin, int l_end, const uint8_t* attn_skip,
+                     int score_site, int score_chain, int score_group, float* batch_scores_dev, int score_ld);
 
 /* a3 tail + a4: final LayerNorm on the CLS rows, classifier, first-max-index argmax (torch.argmax rule),
  * comparison with labels.  Any of logits_dev [n,classes] f32, pred_dev [n] i32, labels_dev [n] i64 +

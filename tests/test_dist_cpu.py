@@ -32,10 +32,10 @@ class OracleBackedEngine:
         return t.float().reshape(-1, self.dim).contiguous()
 
     @torch.no_grad()
-    def layers(self, x, n, l_begin=0, l_end=None, attn_skip=None, score_site="none", score_chain="fp32", batch_scores=None):
+    def layers(self, x, n, l_begin=0, l_end=None, attn_skip=None, score_site="none", score_chain="fp32", batch_scores=None, x_in=None):
         l_end = self.depth if l_end is None else l_end
         skip = set(int(i) for i in (attn_skip or []))
-        t = x.view(n, self.tokens, self.dim)
+        t = (x if x_in is None else x_in[: x.shape[0]]).view(n, self.tokens, self.dim)
         with torch.autocast("cpu", enabled=True):
             for l in range(l_begin, l_end):
                 b = self.m.blocks[l]

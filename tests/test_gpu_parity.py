@@ -1363,3 +1363,40 @@ def test_patch_embed_with_lds_staged_patch_tiles_gives_the_im2col_paths_bits(gpu
                 assert float(err.max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-6, (cfg, n, float(err.max()))
                 assert torch.equal(x[:, 0, :], (w["cls"].to(gpu) + w["pos"].to(gpu)[:, :1, :]).view(1, dim).expand(n, dim))
         eng.close()
+
+
+def test_out_of_place_block_input_equals_copy_then_in_place(gpu):
+    """ssp2_layers_from (VitEngine.layers(x_in=...)): the stream entering the first block is read from x_in, the first
+    residual epilogue writes x = x_in + delta, the rest runs in place — what the layer-major search uses to start candidate
+    l from the baseline's slot without the 194 MB snapshot copy.  Must equal `x.copy_(x_in); layers(x)` bit for bit and
+    leave x_in untouched: attention skipped (first residual add = fc2) and not skipped (= out-proj), one and two blocks,
+    a launch on the persistent 256 x 256 kernel (7880 rows) and one on the 128 x 128 kernel (591 rows), and with a batch
+    LIST embedded into one token matrix (no torch.cat) against the concatenated tensor."""
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_base_patch16_224_d3", classes=10, seed=8, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
+    eng = VitEngine(w, max_images=40)
+    g = torch.Generator().manual_seed(4)
+    for n in (40, 3):
+        px = torch.randn(n, 3, 224, 224, generator=g).to(gpu)
+        x0 = eng.embed(px)
+        for (lb, le, skip) in ((0, 1, [0]), (1, 2, None), (0, 2, [1]), (1, 3, [1, 2])):
+            ref = x0.clone(); eng.layers(ref, n, lb, le, skip)
+            src = x0.clone(); out = torch.full_like(x0, float("nan"))
+            eng.layers(out, n, lb, le, skip, x_in=src)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (n, lb, le, skip)
+            assert torch.equal(src, x0), "x_in was modified"
+    # batch lists: contiguous and slab layouts
+    parts = [torch.randn(8, 3, 224, 224, generator=g).to(gpu) for _ in range(3)] + [torch.randn(5, 3, 224, 224, generator=g).to(gpu)]
+    cat = torch.cat(parts, 0)
+    assert torch.equal(eng.embed(parts), eng.embed(cat))
+    a, b = eng.embed(parts, group=8), eng.embed(cat, group=8)
+    mpad, ntok = eng.rows(8, 8), eng.tokens
+    mpad = (8 * ntok + 255) // 256 * 256
+    valid = torch.cat([torch.arange(s0 * mpad, s0 * mpad + min(8, 29 - s0 * 8) * ntok) for s0 in range(4)]).to(gpu)
+    assert torch.equal(a[valid], b[valid])
+    pads = torch.cat([torch.arange(s0 * mpad + 8 * ntok, (s0 + 1) * mpad) for s0 in range(3)]).to(gpu)
+    assert float(a[pads].abs().max()) == 0.0 and float(b[pads].abs().max()) == 0.0       # pad rows zeroed (only they are cleared now)
+    assert torch.equal(eng.forward_scores(parts, "pre_gelu", "fp32", 8), eng.forward_scores(cat, "pre_gelu", "fp32", 8))
+    eng.close()
