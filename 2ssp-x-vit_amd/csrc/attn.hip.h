@@ -531,3 +531,192 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// d_h = 80 (ViT-H/14: 257 tokens, 9 query tiles), full attention, persistent form.  K + V of one head are 92 KB, so the two
+// whole-item buffers of attn64_persist_kernel do not fit the 160 KiB; and nine query tiles do not leave a wave over for a
+// producer.  Instead: ONE 8-wave workgroup per CU walks the (image, head) items with a ring of TWO K buffers and ONE V buffer
+// (3 x 45 KiB + slack) and every wave is a consumer that also issues its share of the LDS-DMA (6 one-KiB pieces per operand;
+// the 45 pieces of an operand are dealt round-robin, three waves re-send a piece to keep the count uniform).  Two barriers per item:
+//     B1(i)  everybody has finished P V of item i-1 and its K(i) pieces have landed (vmcnt(0))
+//            -> issue [Q fragments of item i+1 | V(i) -> V | K(i+1) -> K[(i+1) & 1]]; S = K Q^T and the softmax of item i run on K[i & 1]
+//     B2(i)  behind vmcnt(6): V(i) has landed, K(i+1) may still be in flight -> O = P V from V, output stores
+// K[(i+1) & 1] was last read by item i-1 (finished before B2(i-1)), V by P V of item i-1 (finished before B1(i)).  So the next
+// item's K and this item's V arrive during arithmetic; the one-item kernel (one 4-wave workgroup per CU at d_h = 80) waits for
+// every byte of K and V before its first MFMA.  Waves 0..7 take query tiles 0..7, wave 0 also the ninth (one valid query).
+// The per-tile arithmetic is the instruction order of attn_fwd_kernel<80, NT, false> (DMA80 layout: 160-byte rows, unswizzled):
+// bit-identical outputs (tests flip SSP2_OPT_ATTN_PERSIST).
+template <int NT>
+__global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
+                                                            int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
+                                                            int reverse = 0) {
+  static_assert(NT >= 8 && NT <= 9, "waves 0..7 take tiles 0..7, wave 0 the ninth");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DH = 80, KS = 5, DT = 3, CH = 10, NKEY = NT * 32, RSB = 160, KV = NKEY * RSB;     // 46080 B per operand
+  constexpr int NP = NKEY * CH / 64;                                                              // 45 one-KiB pieces per operand
+  static_assert((NKEY * CH) % 64 == 0, "whole DMA pieces");
+  constexpr int PPW = (NP + 7) / 8;                                                               // 6 pieces per wave and operand
+  char* const K0 = smem;
+  char* const Vb = smem + 2 * KV;                                                                  // + 64 bytes of slack behind V (read past the last row's 160 B)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int G = gridDim.x;
+  auto row0_of = [&](int it, int& head) -> size_t { if (reverse) it = n_items - 1 - it; const int img = it / heads; head = it - img * heads; return (size_t)row_of(rm, img); };
+
+  auto issue = [&](int it, int which /* 1 = K, 2 = V */, char* dst) {
+    int head; const size_t r0 = row0_of(it, head);
+    const bf16* base = qkv + r0 * ld + head * DH + which * dim;
+    int ls = lane;
+    asm volatile("" : "+v"(ls));                               // opaque: the per-lane source offsets are re-formed per call, not carried across the item loop in registers
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      int piece = wave + 8 * j;
+      piece = piece < NP ? piece : piece - 8;                  // the last round re-sends a piece (same bytes to the same place)
+      const int gch = piece * 64 + ls, row = gch / CH, c = gch - row * CH;
+      const int rc = row < tokens ? row : tokens - 1;
+      glds16(base + (size_t)rc * ld + c * 8, dst + piece * 1024);
+    }
+  };
+  auto load_q_asm = [&](int it, int qt, bf16x8 (&dst)[KS]) {
+    int head; const size_t r0 = row0_of(it, head);
+    int ls = lane;
+    asm volatile("" : "+v"(ls));
+    const int q = qt * 32 + (ls & 31);
+    const int qc = q < tokens ? q : tokens - 1;
+    const bf16* qp = qkv + (r0 + qc) * ld + head * DH + 8 * (ls >> 5);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      f32x4 t;
+      asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(t) : "v"(qp), "n"(32 * s) : "memory");
+      dst[s] = __builtin_bit_cast(bf16x8, t);
+    }
+  };
+
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
+  const int v_lane_off = (4 * lh + tr_q) * RSB + (16 * tr_g + 4 * tr_p) * 2;
+  const bool two = (NT == 9) && wave == 0;                    // wave 0 also takes the ninth tile
+  // Q fragments: qa = the wave's tile of the CURRENT item, na = of the next item (in flight during this one).  Wave 0 fetches its
+  // ninth tile's fragments into qa once the first tile's scores are done (qa is dead then) and they land during its P V.
+  // 512 threads = 256 registers per lane: 144 score + 48 output accumulators leave room for two fragment sets (three spilled).
+  bf16x8 qa[KS], na[KS];
+
+  int it = blockIdx.x;
+  if (it < n_items) {
+    issue(it, 1, K0);
+    load_q_asm(it, wave, na);
+  }
+  for (int b = 0; it < n_items; it += G, b ^= 1) {            // workgroup-uniform trip count
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                              // B1(i)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qa[s] = na[s];
+    const bool more = it + G < n_items;
+    if (more) load_q_asm(it + G, wave, na);
+    issue(it, 2, Vb);
+    if (more) issue(it + G, 1, K0 + (b ^ 1) * KV);
+    const char* Ks = K0 + b * KV;
+    int head; const size_t r0 = row0_of(it, head);
+
+    // S^T = K Q^T and the softmax for the wave's tile(s); the score accumulators stay in registers across B2
+    f32x16 sacc[NT];
+    float inv;
+    auto scores = [&](const bf16x8 (&qf)[KS]) {
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[kt][i] = 0.f;
+        const char* kp = Ks + (kt * 32 + l31) * RSB + 16 * lh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const bf16x8 kf = *(const bf16x8*)(kp + 32 * s);
+          sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
+        }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (kt == NT - 1) {
+            const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            if (key >= tokens) sacc[kt][i] = -INFINITY;
+          }
+          mx = fmaxf(mx, sacc[kt][i]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float c2 = scale * 1.44269504088896340736f;
+      const float mc = -mx * c2;
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][i], c2, mc));
+          sacc[kt][i] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 32);
+      inv = 1.0f / sum;
+    };
+    auto pv_store = [&](int qt) {
+      f32x16 oacc[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s2 + j];
+          const char* vp = Vb + (kt * 32 + 16 * s2) * RSB + v_lane_off;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp + dt * 64));
+            const bf16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp + dt * 64 + 8 * RSB));
+            bf16x8 vf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { vf[j] = v1[j]; vf[4 + j] = v2[j]; }
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
+          }
+        }
+      }
+      const int q = qt * 32 + l31;
+      if (q < tokens) {
+        bf16* op = out + (r0 + q) * ldo + head * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = dt * 32 + 8 * g4 + 4 * lh;
+            if (d0 < DH) {
+              bf16x4 o4;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o4[j] = (bf16)(oacc[dt][4 * g4 + j] * inv);
+              *(bf16x4*)(op + d0) = o4;
+            }
+          }
+      }
+    };
+
+    scores(qa);
+    // B2(i): V(i) has landed on every wave (its 6 pieces are older than the 6 of K(i+1), when there is a next item)
+    if (more) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (two) load_q_asm(it, 8, qa);                            // behind B2, so that the counted wait above keeps its meaning
+    pv_store(wave);
+    if (two) {                                                 // the ninth tile: K[i & 1] and V are both still valid
+      {   // its fragments have landed (and, older, K(i+1)): a wait the uses of qa cannot move above
+        f32x4 t0 = __builtin_bit_cast(f32x4, qa[0]), t1 = __builtin_bit_cast(f32x4, qa[1]), t2 = __builtin_bit_cast(f32x4, qa[2]),
+              t3 = __builtin_bit_cast(f32x4, qa[3]), t4 = __builtin_bit_cast(f32x4, qa[4]);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4) :: "memory");
+        qa[0] = __builtin_bit_cast(bf16x8, t0); qa[1] = __builtin_bit_cast(bf16x8, t1); qa[2] = __builtin_bit_cast(bf16x8, t2);
+        qa[3] = __builtin_bit_cast(bf16x8, t3); qa[4] = __builtin_bit_cast(bf16x8, t4);
+      }
+      scores(qa);
+      pv_store(8);
+    }
+  }
+}
+

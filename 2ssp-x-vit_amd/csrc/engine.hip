@@ -278,7 +278,8 @@ static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const flo
   // one instantiation per row width in 256-element steps: the row lives in MAXV float4 registers per lane, and a
   // wider instantiation than needed drags predicated dead chunks along (ViT-L/16 on <8>: 3.1 TB/s; on <4>: see DESIGN)
   const int rev = rows >= kBigTileMinRows ? next_dir(e) : 0;
-#define LN_CASE(V) hipLaunchKernelGGL(layernorm_bf16_kernel<V>, grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8, rev)
+#define LN_CASE(V) do { if (D == 256 * V) hipLaunchKernelGGL((layernorm_bf16_kernel<V, true>), grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8, rev); \
+                        else hipLaunchKernelGGL((layernorm_bf16_kernel<V, false>), grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8, rev); } while (0)
   if (D <= 256 * 1) LN_CASE(1);
   else if (D <= 256 * 2) LN_CASE(2);
   else if (D <= 256 * 3) LN_CASE(3);
@@ -321,6 +322,24 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
       hipLaunchKernelGGL((attn64_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
+  }
+  if constexpr (DH == 80 && !CLS && NT >= 8 && NT <= 9) {
+    // persistent form for d_h = 80 (ViT-H/14): two K buffers + one V buffer, every wave consumer and DMA issuer (attn.hip.h)
+    if (e->opt[SSP2_OPT_ATTN_PERSIST]) {
+      constexpr int psmem = 3 * NT * 32 * 160 + 64;
+      static bool pattr_done[kMaxDevices] = {};
+      if (!pattr_done[e->dev]) {
+        HIPCHK(hipFuncSetAttribute((const void*)attn80_persist_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, psmem));
+        pattr_done[e->dev] = true;
+      }
+      const long items = (long)e->d.heads * n;
+      if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
+      const int rev = next_dir(e);
+      hipLaunchKernelGGL((attn80_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
                          e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev);
       HIPCHK(hipGetLastError());
       return 0;

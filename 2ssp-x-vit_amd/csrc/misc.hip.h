@@ -48,7 +48,11 @@ __global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ 
 // (two-pass mean / variance in fp32), 16-byte loads and 8-byte stores (lane owns float4 chunks lane, lane+64, ..).
 // Row r is read at x + r*in_stride (in_stride = tokens*dim picks the CLS rows for the classifier head).
 // D multiple of 4, D <= 256*MAXV.
-template <int MAXV>
+// FULL: D = 256 * MAXV exactly (ViT-B 768, ViT-L 1024, ViT-H 1280): no chunk is predicated, the row's loads, statistics and
+// stores are straight-line code.  Round 2 predicated every chunk (`if (chunk < nv)`); for MAXV = 5 the merges of the
+// conditionally loaded row cost 270 register moves and 138 VGPRs — 3 waves per SIMD, 3.1 TB/s on ViT-H/14 against 5.7 for the
+// narrower rows (profiles/r03_d_other_models.jsonl).  The results do not depend on FULL (same ln_row_stats / ln_chunk_write).
+template <int MAXV, bool FULL = false>
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, size_t in_stride,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16* __restrict__ y,
@@ -63,15 +67,20 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   f32x4 v[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
-    if (i * 64 + lane < nv) v[i] = xr[i * 64 + lane];
+    if (FULL || i * 64 + lane < nv) v[i] = xr[i * 64 + lane];
   float mean, rstd;
-  ln_row_stats<MAXV, false>(v, lane, nv, 1.0f / (float)D, eps, mean, rstd);
-  // gamma / beta only now (L2 hits): held across the statistics they cost 24 registers per wave and three of its eight
-  // waves per SIMD — the kernel lives on memory-level parallelism (84 VGPRs: 60 us for 63040 rows, 32: 50 us)
+  ln_row_stats<MAXV, FULL>(v, lane, nv, 1.0f / (float)D, eps, mean, rstd);
+  // gamma / beta only now (L2 hits): held across the statistics they cost 8 registers per chunk and most of the eight waves per
+  // SIMD — the kernel lives on memory-level parallelism (84 VGPRs: 60 us for 63040 rows, 32: 50 us).  The lane index their
+  // addresses are formed from is made to DEPEND on the statistics: for MAXV = 5 and 8 (ViT-H/14, row widths up to 2048) hipcc
+  // otherwise hoists all 2 x MAXV loads above them — 138 / 188 VGPRs, 3 / 2 waves per SIMD, 3.1 TB/s where the narrower
+  // instantiations (38-45 VGPRs) run at 5.7 (round 3: profiles/r03_d_other_models.jsonl).
+  int lane_gb = lane;
+  asm volatile("" : "+v"(lane_gb) : "v"(rstd));
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = i * 64 + lane;
-    if (c < nv) {
+    const int c = i * 64 + lane_gb;
+    if (FULL || c < nv) {
       const f32x4 g4 = ((const f32x4*)gamma)[c], b4 = ((const f32x4*)beta)[c];
       // fp8 mode: e4m3 bytes (of the bf16-rounded value), out_ld in bytes
       if (y8) ln_chunk_write<true>(v[i], mean, rstd, g4, b4, y8 + (size_t)row * out_ld, c);

@@ -383,13 +383,15 @@ def test_cls_only_tail_is_bit_identical_to_full_last_block(gpu, cfg):
         assert torch.equal(lt, lf) and torch.equal(pt, pf) and int(ct) == int(cf)
 
 
-@pytest.mark.parametrize("cfg,img", [("vit_small_patch16_224_d2", 224), ("vit_small_patch16_224_d2", 192)])
+@pytest.mark.parametrize("cfg,img", [("vit_small_patch16_224_d2", 224), ("vit_small_patch16_224_d2", 192), ("vit_huge_patch14_224_d2", 224)])
 def test_persistent_attention_is_bit_identical_to_the_one_item_kernel(gpu, cfg, img):
     """d_h = 64 attention runs as a persistent producer / consumer kernel (attn64_persist_kernel: double-buffered K/V,
-    one query tile per wave); SSP2_ATTN_PERSIST=0 routes the same launch to attn_fwd_kernel.  Same per-tile arithmetic
+    one query tile per wave); SSP2_OPT_ATTN_PERSIST = 0 routes the same launch to attn_fwd_kernel.  Same per-tile arithmetic
     order => the residual stream after two blocks must agree BIT FOR BIT: for item counts below, equal to a ragged
     multiple of, and far above the CU count, in the contiguous and in the slab row layout, for 197 tokens (7 query
-    tiles) and 145 tokens (5 tiles: two idle waves that only meet the barriers)."""
+    tiles) and 145 tokens (5 tiles: two idle waves that only meet the barriers).  Round 3: d_h = 80 / 257 tokens / nine
+    query tiles (ViT-H/14) on attn80_persist_kernel (two K buffers + one V buffer, every wave consumer and DMA issuer, wave 0
+    takes the ninth tile), 16 heads: 16 .. 3072 items on 256 CUs."""
     from ssp2vit.engine import VitEngine
     from ssp2vit.weights import synthetic_weights
     w = synthetic_weights(cfg, classes=10, seed=11, std=0.05, eps=1e-6, bias_std=0.02)
