@@ -125,11 +125,54 @@ __device__ __forceinline__ void ln_chunk_write(const f32x4& v, float mean, float
   if constexpr (OUT8) *(uint32_t*)((uint8_t*)y + c * 4) = pack_e4m3x4_from((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
   else *(bf16x4*)((bf16*)y + c * 4) = o;
 }
+// Maximum over the 64 lanes on the VALU (the pattern of wave_sum_dpp).
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)));
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  v = fmaxf(a, b); a = v; b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+// fp8 mode with PER-ROW activation scales (round 3): the row's bf16-rounded LayerNorm values o are written as
+// e4m3(o * 448 / amax(|o|)) and *ascale_row = amax / 448 — the projection that reads the row multiplies its accumulators by it
+// (gemm256.hip.h, GemmArgs.ascale).  The bare saturating cast of round 2 clipped at +-448 and spent the e4m3 subnormals on every
+// value below 2^-6; with the row's own scale the largest element sits at the top of the range whatever gamma / beta a model has.
+template <int MAXV, bool FULL>
+__device__ __forceinline__ void ln_row_write8_scaled(const f32x4 (&v)[MAXV], int lane, int nv, float mean, float rstd, const f32x4 (&g4)[MAXV],
+                                                     const f32x4 (&b4)[MAXV], uint8_t* y8, float* ascale_row) {
+#pragma clang fp contract(off)
+  f32x4 o[MAXV];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (FULL || i * 64 + lane < nv) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[i][k] = (float)(bf16)__builtin_fmaf((v[i][k] - mean) * rstd, g4[i][k], b4[i][k]);
+        amax = fmaxf(amax, fabsf(o[i][k]));
+      }
+    }
+  amax = wave_max_dpp(amax);
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = amax > 0.f ? 448.0f / amax : 1.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (FULL || i * 64 + lane < nv)
+      *(uint32_t*)(y8 + (i * 64 + lane) * 4) = pack_e4m3x4_from(o[i][0] * inv, o[i][1] * inv, o[i][2] * inv, o[i][3] * inv);
+  if (lane == 0) *ascale_row = sc;
+}
 template <int MAXV, bool FULL, bool OUT8>
 __device__ __forceinline__ void ln_row_finish(const f32x4 (&v)[MAXV], int lane, int nv, float inv_d, float eps, const f32x4 (&g4)[MAXV],
-                                              const f32x4 (&b4)[MAXV], void* y) {
+                                              const f32x4 (&b4)[MAXV], void* y, float* ascale_row = nullptr) {
   float mean, rstd;
   ln_row_stats<MAXV, FULL>(v, lane, nv, inv_d, eps, mean, rstd);
+  if constexpr (OUT8) {
+    if (ascale_row) { ln_row_write8_scaled<MAXV, FULL>(v, lane, nv, mean, rstd, g4, b4, (uint8_t*)y, ascale_row); return; }
+  }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
     if (FULL || i * 64 + lane < nv) ln_chunk_write<OUT8>(v[i], mean, rstd, g4[i], b4[i], y, i * 64 + lane);

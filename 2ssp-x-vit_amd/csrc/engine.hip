@@ -116,6 +116,7 @@ struct ssp2_engine {
 
   bool fp8 = false;             // ssp2_set_precision(SSP2_PREC_FP8): QKV / fc1 / fc2 of launches with >= 4096 rows on e4m3 MFMA
   uint8_t *hbuf8 = nullptr, *act8 = nullptr;   // LayerNorm output / FFN activation as e4m3 bytes
+  float* hscale = nullptr;                     // per-row activation scale of hbuf8 (amax / 448, written by the LayerNorm)
   int ld8_dim = 0, ld8_int_max = 0;
   float* stage_f32 = nullptr;   // staging buffer of ssp2_load_tensor (host sources)
   size_t stage_cap = 0;
@@ -272,14 +273,14 @@ static int launch_gemm_small(ssp2_engine* e, GemmArgs g, int klass) {
 }
 
 static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const float* g, const float* b, bf16* y,
-                     int out_ld, int rows, int D, RowMap gather = RowMap{0, 0, 0}, uint8_t* y8 = nullptr) {
+                     int out_ld, int rows, int D, RowMap gather = RowMap{0, 0, 0}, uint8_t* y8 = nullptr, float* ascale = nullptr) {
   ProfScope ps(e, SSP2_K_LN, 0, (double)rows * D * (4.0 + (y8 ? 1.0 : 2.0)));     // fp32 row in, bf16 / e4m3 row out
   dim3 grid((rows + 3) / 4), blk(256);
   // one instantiation per row width in 256-element steps: the row lives in MAXV float4 registers per lane, and a
   // wider instantiation than needed drags predicated dead chunks along (ViT-L/16 on <8>: 3.1 TB/s; on <4>: see DESIGN)
   const int rev = rows >= kBigTileMinRows ? next_dir(e) : 0;
-#define LN_CASE(V) do { if (D == 256 * V) hipLaunchKernelGGL((layernorm_bf16_kernel<V, true>), grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8, rev); \
-                        else hipLaunchKernelGGL((layernorm_bf16_kernel<V, false>), grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8, rev); } while (0)
+#define LN_CASE(V) do { if (D == 256 * V) hipLaunchKernelGGL((layernorm_bf16_kernel<V, true>), grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8, rev, ascale); \
+                        else hipLaunchKernelGGL((layernorm_bf16_kernel<V, false>), grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8, rev, ascale); } while (0)
   if (D <= 256 * 1) LN_CASE(1);
   else if (D <= 256 * 2) LN_CASE(2);
   else if (D <= 256 * 3) LN_CASE(3);
@@ -639,6 +640,7 @@ int ssp2_set_precision(ssp2_handle e, int mode) {
     e->ld8_int_max = ceil_to(e->ld_int_max, 128);
     if ((rc = dalloc(e, &e->hbuf8, (size_t)e->rows_cap * e->ld8_dim, true))) return rc;
     if ((rc = dalloc(e, &e->act8, (size_t)e->rows_cap * e->ld8_int_max, true))) return rc;
+    if ((rc = dalloc(e, &e->hscale, (size_t)e->rows_cap, true))) return rc;
   }
   e->fp8 = true;
   return 0;
@@ -734,7 +736,7 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
   if (xsrc != x && e->opt[SSP2_OPT_LN_FUSION]) return fail(SSP2_EINVAL, "ssp2_layers_from: out-of-place input with the fused LayerNorm is not supported");
   auto set_ln = [&](GemmArgs& a, const float* gm, const float* bt, bool to_fp8) {
     a.ln_g = gm; a.ln_b = bt; a.ln_eps = e->d.ln_eps;
-    if (to_fp8) { a.ln_out8 = e->hbuf8; a.ln_ld = e->ld8_dim; } else { a.ln_out = e->hbuf; a.ln_ld = D; }
+    if (to_fp8) { a.ln_out8 = e->hbuf8; a.ln_ld = e->ld8_dim; a.ln_ascale = e->hscale; } else { a.ln_out = e->hbuf; a.ln_ld = D; }
   };
   for (int l = l_begin; l < l_end; ++l) {
     Layer& L = e->layers[l];
@@ -747,8 +749,8 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
       GemmArgs q{};
       q.bias = L.qkv.b; q.M = M; q.N = 3 * D; q.tiles_n = L.qkv.rows_pad / GEMM_BN; q.out = e->qkvbuf; q.ldo = 3 * D;
       if (f8) {
-        if (!h_ready && (rc = launch_ln(e, xsrc, D, L.ln1_g, L.ln1_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
-        q.A = (const bf16*)e->hbuf8; q.lda = e->ld8_dim; q.W = (const bf16*)L.qkv.w8; q.ldw = L.qkv.ld8; q.K = e->ld8_dim; q.wscale = L.qkv.wscale;
+        if (!h_ready && (rc = launch_ln(e, xsrc, D, L.ln1_g, L.ln1_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8, e->hscale))) return rc;
+        q.A = (const bf16*)e->hbuf8; q.lda = e->ld8_dim; q.W = (const bf16*)L.qkv.w8; q.ldw = L.qkv.ld8; q.K = e->ld8_dim; q.wscale = L.qkv.wscale; q.ascale = e->hscale;
         if ((rc = launch_gemm256<EPI_BF16, 0, true>(e, q, SSP2_K_GEMM_QKV))) return rc;
       } else {
         if (!h_ready && (rc = launch_ln(e, xsrc, D, L.ln1_g, L.ln1_b, e->hbuf, D, M, D))) return rc;
@@ -771,8 +773,8 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
     GemmArgs f{};
     f.bias = L.fc1.b; f.M = M; f.tiles_n = L.fc1.rows_pad / GEMM_BN;
     if (f8_fc1) {
-      if (!h_ready && (rc = launch_ln(e, xsrc, D, L.ln2_g, L.ln2_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8))) return rc;
-      f.A = (const bf16*)e->hbuf8; f.lda = e->ld8_dim; f.W = (const bf16*)L.fc1.w8; f.ldw = L.fc1.ld8; f.K = e->ld8_dim; f.wscale = L.fc1.wscale;
+      if (!h_ready && (rc = launch_ln(e, xsrc, D, L.ln2_g, L.ln2_b, nullptr, e->ld8_dim, M, D, RowMap{0, 0, 0}, e->hbuf8, e->hscale))) return rc;
+      f.A = (const bf16*)e->hbuf8; f.lda = e->ld8_dim; f.W = (const bf16*)L.fc1.w8; f.ldw = L.fc1.ld8; f.K = e->ld8_dim; f.wscale = L.fc1.wscale; f.ascale = e->hscale;
       f.N = ld8_int; f.out = (bf16*)e->act8; f.ldo = ld8_int;      // e4m3 bytes out; the pad columns up to 128 are written (zeros)
     } else {
       if (!h_ready && (rc = launch_ln(e, xsrc, D, L.ln2_g, L.ln2_b, e->hbuf, D, M, D))) return rc;

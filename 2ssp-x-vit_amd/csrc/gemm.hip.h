@@ -58,10 +58,12 @@ struct GemmArgs {
   // K a multiple of 128), acc is multiplied by wscale[n] (the weight row's dequantisation scale) before the bias;
   // EPI_FC1 then writes e4m3 bytes to `out` (ldo in bytes) for the fp8 fc2 that follows
   const float* wscale;
+  const float* ascale;        // fp8: per-ROW dequantisation scale of the A operand ([M], written by the LayerNorm that produced it) or nullptr (= 1)
   // LayerNorm fused behind the residual epilogue (gemm256 kernel, EPI_RESID with SCORE = N / 256 only): once a workgroup has
   // written all N / 256 column tiles of a 256-row panel of x it normalises those rows (gamma / beta fp32 [N], eps) into
   // ln_out (bf16, ld ln_ld elements) or, fp8 mode, ln_out8 (e4m3 bytes, ld ln_ld bytes) — the operand of the next projection
   const float* ln_g; const float* ln_b; bf16* ln_out; uint8_t* ln_out8; int ln_ld; float ln_eps;
+  float* ln_ascale;           // with ln_out8: the rows' activation scales ([M]) the fused phase writes beside the e4m3 bytes
 #ifdef GEMM_STAMPS
   unsigned long long* stamps; // diagnostic build only: [blocks][64] s_memtime values of wave 0
 #endif

@@ -135,6 +135,15 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   int m0 = 0, n0 = 0;
   float bias_next = 0.f;                                // bias[n0 + wn*64 + lane] of the tile being prefetched
   float wsc_next = 1.f;                                 // F8: wscale[...] of the same column
+  float asc_next[4] = {1.f, 1.f, 1.f, 1.f};             // F8: ascale[row] of the lane's four rows (row0 + a*32 + l31) of that tile
+  auto load_asc = [&](int m0_) {                        // (rows past M: the last valid row's — never stored)
+    if constexpr (F8) {
+      if (g.ascale) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { int r = m0_ + wm * 128 + a * 32 + l31; r = r < g.M ? r : g.M - 1; asc_next[a] = g.ascale[r]; }
+      }
+    }
+  };
   auto set_tile = [&](int tile) {
     int tm, tn;
     if (g.reverse) tile = ntiles - 1 - tile;
@@ -203,6 +212,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     set_tile(tile);
     bias_next = g.bias[n0 + wn * 64 + lane];
     if (F8) wsc_next = g.wscale[n0 + wn * 64 + lane];
+    load_asc(m0);
     stage_b(C::B0, 0);
     stage_a(C::A0, 0);
     if (nk > 1) stage_a(C::A1, 1);
@@ -240,6 +250,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     asm volatile("v_mov_b32 %0, %0" : "+v"(bias_lane));
     float wsc_lane = wsc_next;
     if (F8) asm volatile("v_mov_b32 %0, %0" : "+v"(wsc_lane));
+    float asc[4] = {asc_next[0], asc_next[1], asc_next[2], asc_next[3]};     // taken over here for the same reason as the bias
+    if (F8) asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(asc[0]), "+v"(asc[1]), "+v"(asc[2]), "+v"(asc[3]));
     TSTAMP(41);
     // ---- main loop: two wave groups in ping-pong.  A UNIT is half a K-tile: LOAD = 12 fragment reads
     // (ds_read_b128), COMPUTE = 16 MFMAs with 4 LDS-DMA pieces issued BETWEEN the MFMAs (behind pairs 0, 2, 4, 6; s_memtime stamps: a piece
@@ -434,6 +446,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       }
       bias_next = g.bias[n0 + wn * 64 + lane];
       if (F8) wsc_next = g.wscale[n0 + wn * 64 + lane];
+      load_asc(m0);
     }
     TSTAMP(43);
     // Lane-derived epilogue constants are recomputed per tile behind an opaque copy of the lane id: hoisted out of the
@@ -469,7 +482,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     }
     // pre-activation of element (a, b, 4q + r) before the bf16 rounding: acc + bias, or acc * wscale + bias on fp8 operands
     auto pre_f32 = [&](int a, int b, int q, int r) -> float {
-      if constexpr (F8) return fmaf(acc[a][b][4 * q + r], sc[b][q][r], bb[b][q][r]);
+      if constexpr (F8) return fmaf(acc[a][b][4 * q + r] * asc[a], sc[b][q][r], bb[b][q][r]);     // asc = 1 without activation scales: exact
       else return acc[a][b][4 * q + r] + bb[b][q][r];
     };
     counted = full && SWAP;
@@ -499,6 +512,15 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       float ssq[2][2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};     // [pass h][segment][b]
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+        // fp8 activation scales of the pass's rows (plain order: register i of sub-tile a2 is row a2*32 + (i&3) + 8*(i>>2) + 4*lh)
+        float arow[2][16];
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            arow[a2][i] = 1.f;
+            if constexpr (F8) { if (g.ascale) arow[a2][i] = g.ascale[min(row0 + h * 64 + a2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * lhe, g.M - 1)]; }
+          }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const float bias = bias2[b];
@@ -513,7 +535,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
               const int rw = a2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * lhe;     // row inside the 64-row pass (i even: rw, rw+1)
-              const uint32_t pk = F8 ? pack_bf16x2(fmaf(acc[a][b][i], scl, bias), fmaf(acc[a][b][i + 1], scl, bias))
+              const uint32_t pk = F8 ? pack_bf16x2(fmaf(acc[a][b][i] * arow[a2][i], scl, bias), fmaf(acc[a][b][i + 1] * arow[a2][i + 1], scl, bias))
                                      : pack_bf16x2(acc[a][b][i] + bias, acc[a][b][i + 1] + bias);
               f32x2 pre;
               const f32x2 gl = gelu_erf_pk(pk, pre);
@@ -802,7 +824,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             int r = wave + 8 * i;
             r = r < rows_here ? r : rows_here - 1;
             const size_t ro = (size_t)(cur_m0 + r) * g.ln_ld;
-            ln_row_finish<LNV, true, OUT8>(src, ll, nv, inv_d, g.ln_eps, g4, b4, OUT8 ? (void*)(g.ln_out8 + ro) : (void*)(g.ln_out + ro));
+            ln_row_finish<LNV, true, OUT8>(src, ll, nv, inv_d, g.ln_eps, g4, b4, OUT8 ? (void*)(g.ln_out8 + ro) : (void*)(g.ln_out + ro),
+                                           (OUT8 && g.ln_ascale) ? g.ln_ascale + cur_m0 + r : nullptr);
           };
           using N1 = std::integral_constant<int, LNV>;        // younger than the set: the other set's loads
           using N2 = std::integral_constant<int, 2 * LNV>;    // ... and the previous row's stores (waiting for THOSE cost ~1 us per row)

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16* __restrict__ y,
                                                             int out_ld, int rows, int D, float eps, RowMap gather,
-                                                            uint8_t* __restrict__ y8 = nullptr, int reverse = 0) {
+                                                            uint8_t* __restrict__ y8 = nullptr, int reverse = 0,
+                                                            float* __restrict__ ascale = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = (reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -77,6 +78,14 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   // instantiations (38-45 VGPRs) run at 5.7 (round 3: profiles/r03_d_other_models.jsonl).
   int lane_gb = lane;
   asm volatile("" : "+v"(lane_gb) : "v"(rstd));
+  if (y8 && ascale) {                                 // fp8 mode, per-row activation scale (common.hip.h ln_row_write8_scaled)
+    f32x4 g4[MAXV], b4[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (FULL || i * 64 + lane_gb < nv) { g4[i] = ((const f32x4*)gamma)[i * 64 + lane_gb]; b4[i] = ((const f32x4*)beta)[i * 64 + lane_gb]; }
+    ln_row_write8_scaled<MAXV, FULL>(v, lane_gb, nv, mean, rstd, g4, b4, y8 + (size_t)row * out_ld, ascale + row);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = i * 64 + lane_gb;
