@@ -841,7 +841,7 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
 }
 
 static int head_impl(ssp2_engine* e, const float* x, size_t in_stride, int n, float* logits_dev, int32_t* pred, const int64_t* labels,
-                     int64_t* correct, RowMap gather = RowMap{0, 0, 0}) {
+                     int64_t* correct, RowMap gather = RowMap{0, 0, 0}, int period = 0) {
   int rc;
   if (!(e->misc_set[2] && e->misc_set[3] && e->head.w_set && e->head.b_set)) return fail(SSP2_ESTATE, "final norm / head weights not loaded");
   const int D = e->d.dim;
@@ -854,7 +854,7 @@ static int head_impl(ssp2_engine* e, const float* x, size_t in_stride, int n, fl
   if (pred || (labels && correct)) {
     ProfScope ps(e, SSP2_K_OTHER);
     hipLaunchKernelGGL(argmax_top1_kernel, dim3((n + 3) / 4), dim3(256), 0, e->stream, lg, n, e->d.classes, pred, labels,
-                       (unsigned long long*)correct);
+                       (unsigned long long*)correct, period);
     HIPCHK(hipGetLastError());
   }
   return 0;
@@ -869,7 +869,21 @@ int ssp2_head(ssp2_handle e, const float* x, int n, int group, float* logits_dev
 
 int ssp2_tail(ssp2_handle e, const float* x, int n, int attn_skip_last, float* logits_dev, int32_t* pred, const int64_t* labels,
               int64_t* correct) {
+  return ssp2_tail_slots(e, x, n, 1, attn_skip_last, logits_dev, pred, labels, correct);
+}
+
+// The tail over `slots` residual streams of n_slot images each, laid side by side in x (slot s = rows [s * n_slot * tokens,
+// (s + 1) * n_slot * tokens)) — the baseline and the candidates of the layer-major search, which all meet the SAME last block
+// and classifier.  One launch sequence for slots * n_slot images instead of one per slot: the tail's launches on n_slot CLS rows
+// (two LayerNorms, q / out-projection / fc1 / fc2 on 320 rows, CLS attention, head, argmax: ~10 kernels of 10-40 us each,
+// latency-bound) were 13 x ~0.25 ms of a 108 ms step.  Per image the arithmetic is unchanged (no result of a row depends on
+// how many rows a launch has), so the counts are the same integers.  labels [n_slot] is shared by the slots, correct [slots].
+int ssp2_tail_slots(ssp2_handle e, const float* x, int n_slot, int slots, int attn_skip_last, float* logits_dev, int32_t* pred,
+                    const int64_t* labels, int64_t* correct) {
   int rc;
+  if (slots <= 0 || n_slot <= 0) return fail(SSP2_EINVAL, "tail: n_slot=%d slots=%d", n_slot, slots);
+  const int n = n_slot * slots;
+  const int period = slots > 1 ? n_slot : 0;
   if ((rc = check_n(e, n))) return rc;
   if (!x) return fail(SSP2_EINVAL, "null x");
   const int D = e->d.dim, M = n * e->tokens, l = e->d.depth - 1;
@@ -905,7 +919,7 @@ int ssp2_tail(ssp2_handle e, const float* x, int n, int attn_skip_last, float* l
   o.A = e->act_cls; o.lda = L.ld_int; o.W = L.fc2.w; o.ldw = L.fc2.ld; o.bias = L.fc2.b;
   o.M = n; o.N = D; o.K = L.ld_int; o.tiles_n = L.fc2.rows_pad / GEMM_BN; o.x = e->x_cls; o.ldx = D;
   if ((rc = launch_gemm<EPI_RESID>(e, o, SSP2_K_GEMM_FC2))) return rc;
-  return head_impl(e, e->x_cls, (size_t)D, n, logits_dev, pred, labels, correct);
+  return head_impl(e, e->x_cls, (size_t)D, n, logits_dev, pred, labels, correct, RowMap{0, 0, 0}, period);
 }
 
 int ssp2_d_int(ssp2_handle e, int layer) {

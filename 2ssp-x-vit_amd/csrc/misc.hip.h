@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256) void score_colsum_halves_kernel(const float* _
 // counts as maximal, as torch does).  correct += (pred == label) with an integer atomic (exact, order-free).
 __global__ __launch_bounds__(256) void argmax_top1_kernel(const float* __restrict__ logits, int n, int classes,
                                                          int32_t* __restrict__ pred, const int64_t* __restrict__ labels,
-                                                         unsigned long long* __restrict__ correct) {
+                                                         unsigned long long* __restrict__ correct, int period = 0) {
+  // period > 0 (ssp2_tail_slots): the n rows are `n / period` SLOTS of `period` images that share one label vector; row r is
+  // compared with labels[r % period] and counted in correct[r / period]
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
@@ -305,7 +307,10 @@ __global__ __launch_bounds__(256) void argmax_top1_kernel(const float* __restric
   }
   if (lane == 0) {
     if (pred) pred[row] = bi;
-    if (labels && correct && labels[row] == (int64_t)bi) atomicAdd(correct, 1ULL);
+    if (labels && correct) {
+      const int li = period > 0 ? row % period : row, ci = period > 0 ? row / period : 0;
+      if (labels[li] == (int64_t)bi) atomicAdd(correct + ci, 1ULL);
+    }
   }
 }
 

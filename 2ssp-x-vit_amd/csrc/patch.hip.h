@@ -26,7 +26,9 @@ struct PatchArgs {
 
 #define PATCH_LDS_BYTES (4 * GEMM_STAGE_BYTES)     // A0 A1 B0 B1; the fp32 epilogue staging (4 x 16 KiB) reuses all of it
 
-__global__ __launch_bounds__(256, 2) void patch_embed_kernel(const PatchArgs g) {
+// (waves per SIMD pinned to 2 = two 64-KiB workgroups per CU: left to its own occupancy target hipcc keeps the kernel at 152 VGPRs
+// and puts the three pixel-tile register sets into scratch memory)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void patch_embed_kernel(const PatchArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const smA = smem;
   char* const smB = smem + 2 * GEMM_STAGE_BYTES;
@@ -54,39 +56,38 @@ __global__ __launch_bounds__(256, 2) void patch_embed_kernel(const PatchArgs g) 
   }
   const int pp2 = g.p * g.p;
   const bool vec = (g.p & 7) == 0;                              // 8 consecutive k = 8 consecutive pixels of one row
-  float av[4][8];
-  auto load_a = [&](int kt) {
+  // The pixel loads of K-tiles kt + 1, kt + 2 and kt + 3 are in flight while tile kt is multiplied: three register sets in a
+  // ring (tile t lives in set t % 3).  One set (the first version) left every iteration waiting ~2 k cycles for loads issued
+  // 16 MFMAs earlier — slower than the im2col image it replaces (profiles/r03_h_step_ab.txt).
+  float av0[4][8], av1[4][8], av2[4][8];
+  auto load_a = [&](int kt, float (&av)[4][8]) __attribute__((always_inline)) {
     const int k0 = kt * GEMM_BK + cc * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      // EVERY chunk issues its loads (a k past K re-reads k = 0 and is zeroed afterwards): the number of vector-memory
+      // operations per K-tile is then the same for every thread — 8 (vec) or 32 — which the counted wait of the loop relies on
       if (vec) {
-        if (k0 < g.K) {
-          const int c = k0 / pp2, rem = k0 - c * pp2;
-          const int ky = rem / g.p, kx = rem - ky * g.p;
-          const float* s = row_px[j] + ((size_t)c * g.img + ky) * g.img + kx;
-          const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + 4);
-          av[j][0] = a[0]; av[j][1] = a[1]; av[j][2] = a[2]; av[j][3] = a[3];
-          av[j][4] = b[0]; av[j][5] = b[1]; av[j][6] = b[2]; av[j][7] = b[3];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) av[j][e] = 0.f;
-        }
+        const int kk = k0 < g.K ? k0 : 0;
+        const int c = kk / pp2, rem = kk - c * pp2;
+        const int ky = rem / g.p, kx = rem - ky * g.p;
+        const float* s = row_px[j] + ((size_t)c * g.img + ky) * g.img + kx;
+        const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + 4);
+        const float z = k0 < g.K ? 1.f : 0.f;
+        av[j][0] = a[0] * z; av[j][1] = a[1] * z; av[j][2] = a[2] * z; av[j][3] = a[3] * z;
+        av[j][4] = b[0] * z; av[j][5] = b[1] * z; av[j][6] = b[2] * z; av[j][7] = b[3] * z;
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int k = k0 + e;
-          float f = 0.f;
-          if (k < g.K) {
-            const int c = k / pp2, rem = k - c * pp2;
-            const int ky = rem / g.p, kx = rem - ky * g.p;
-            f = row_px[j][((size_t)c * g.img + ky) * g.img + kx];
-          }
-          av[j][e] = f;
+          const int k = k0 + e, kk = k < g.K ? k : 0;
+          const int c = kk / pp2, rem = kk - c * pp2;
+          const int ky = rem / g.p, kx = rem - ky * g.p;
+          const float f = row_px[j][((size_t)c * g.img + ky) * g.img + kx];
+          av[j][e] = k < g.K ? f : 0.f;
         }
       }
     }
   };
-  auto store_a = [&](int slot) {
+  auto store_a = [&](int slot, const float (&av)[4][8]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bf16x8 v;
@@ -126,13 +127,22 @@ __global__ __launch_bounds__(256, 2) void patch_embed_kernel(const PatchArgs g) 
 
   const int nk = g.Kpad / GEMM_BK;
   stage_b(0, 0);
-  load_a(0);
-  store_a(0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  load_a(0, av0);
+  if (nk > 1) load_a(1, av1);
+  if (nk > 2) load_a(2, av2);
+  store_a(0, av0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                               // (the DMA of B(0) is waited for at the end of iteration 0's prefetch below)
+  // one K-tile: SET (compile time) = kt % 3 holds tile kt's registers (already in LDS), (SET + 1) % 3 tile kt + 1
+  auto ktile = [&](int kt, auto set_c) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value, NEXT = (SET + 1) % 3;
     const int s = kt & 1;
-    if (kt + 1 < nk) { stage_b(s ^ 1, kt + 1); load_a(kt + 1); }       // slot s^1 was last read in iteration kt-1 (barrier below)
+    if (kt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // B(0) (and the first three pixel tiles) — once
+    if (kt == 0) __syncthreads();
+    if (kt + 1 < nk) stage_b(s ^ 1, kt + 1);                           // slot s^1 was last read in iteration kt-1 (barrier below)
+    if (kt + 3 < nk) {                                                 // tile kt's registers are free: it is in LDS
+      if constexpr (SET == 0) load_a(kt + 3, av0); else if constexpr (SET == 1) load_a(kt + 3, av1); else load_a(kt + 3, av2);
+    }
     const char* As = smA + s * GEMM_STAGE_BYTES;
     const char* Bs = smB + s * GEMM_STAGE_BYTES;
 #pragma unroll
@@ -150,9 +160,19 @@ __global__ __launch_bounds__(256, 2) void patch_embed_kernel(const PatchArgs g) 
         for (int b = 0; b < 2; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_a(s ^ 1);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (kt + 1 < nk) {                                                 // hipcc waits for exactly these registers' loads (the younger ones stay in flight)
+      if constexpr (NEXT == 0) store_a(s ^ 1, av0); else if constexpr (NEXT == 1) store_a(s ^ 1, av1); else store_a(s ^ 1, av2);
+    }
+    // B(kt + 1) must have landed before the next iteration reads it; it is OLDER than the pixel loads of tile kt + 3 (8 per thread)
+    if (kt + 3 >= nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (vec)     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else              asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory");
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 3) {
+    ktile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nk) ktile(kt + 1, std::integral_constant<int, 1>{});
+    if (kt + 2 < nk) ktile(kt + 2, std::integral_constant<int, 2>{});
   }
 
   // ---- epilogue = gemm_bf16_kernel<EPI_PATCH>: fp32 staging [64][64] per wave, then x = bf16(acc + bias) + pos

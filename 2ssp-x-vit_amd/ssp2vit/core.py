@@ -34,6 +34,11 @@ def iter_limited(dataloader: Iterable, limit: Optional[int], progress: bool, des
 DEFAULT_CHUNK_IMAGES = int(os.environ.get("SSP2_CHUNK_IMAGES", "512"))
 DEFAULT_EVAL_CHUNK_IMAGES = int(os.environ.get("SSP2_EVAL_CHUNK_IMAGES", "320"))
 MAX_SLABS = 16          # the engine's workspace carries slack for 16 padded slabs per call (csrc/engine.hip rows_cap)
+# Round-3 host-side changes, each switchable for same-box A/B runs (none changes a result): one tail over all search slots,
+# candidate l started out of place from the baseline's stream, batches embedded into their rows without a concatenated copy
+TAIL_SLOTS = os.environ.get("SSP2_TAIL_SLOTS", "1") != "0"
+OUT_OF_PLACE_START = os.environ.get("SSP2_OUT_OF_PLACE_START", "1") != "0"
+BATCH_LISTS = os.environ.get("SSP2_BATCH_LISTS", "0") != "0"     # measured 0.3-0.5 ms SLOWER per step than one torch.cat (13 x 2 small embed launches): off
 
 
 def _resolve(engine, min_images: int):
@@ -65,6 +70,19 @@ def layer_major_images(engine, slots: int, n: int, device=None) -> int:
 
 
 _COPY_STREAMS = {}
+_INDEX_CACHE = {}
+
+
+def _device_index(values: Sequence[int], device) -> torch.Tensor:
+    """A small int64 index tensor on the device, built once per (device, values): a host list turned into a device tensor inside
+    the search would be a pageable H2D copy, which makes the host wait for everything already enqueued."""
+    key = (str(device), tuple(int(v) for v in values))
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        t = _INDEX_CACHE[key] = torch.tensor(list(key[1]), dtype=torch.int64).to(device)
+        if len(_INDEX_CACHE) > 256:
+            _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
+    return t
 
 
 def _to_device(t: torch.Tensor, device, dtype) -> torch.Tensor:
@@ -180,7 +198,7 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
     ramp = []                    # capacities of the launches that follow the first (host-fed batches only, see below)
 
     def flush():
-        idxs, group, px, _ = ch.take(as_list=getattr(eng, "batch_lists", False))     # VitEngine embeds each batch into its slab: no cat
+        idxs, group, px, _ = ch.take(as_list=BATCH_LISTS and getattr(eng, "batch_lists", False))     # VitEngine embeds each batch into its slab: no cat
         vec = eng.forward_scores(px, site, score_chain, group)      # [len(idxs), L, ld]
         for k, i in enumerate(idxs):
             local.append((i, vec[k]))
@@ -276,7 +294,7 @@ def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images, c
     def cut(k):
         nonlocal px_buf, lb_buf, count
         lb = lb_buf[0] if len(lb_buf) == 1 else torch.cat(lb_buf, 0)
-        if getattr(eng, "batch_lists", False):
+        if BATCH_LISTS and getattr(eng, "batch_lists", False):
             # the chunk's pixels stay a LIST of (views of) the loader's batches: the engine embeds each into its rows of the
             # token matrix — no concatenated copy of the pixels (193 MB per 320-image chunk of ViT-B/16)
             take, rest, left = [], [], k
@@ -416,13 +434,25 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
                     # candidate l: block l without its attention, started STRAIGHT from the baseline's stream (slot 0 still holds
                     # the input of block l) into its own slot — the fc2 epilogue reads slot 0 and writes slot k + 1
                     # (ssp2_layers_from).  Round 2 copied the 194 MB stream into the slot first: 11 copies per step.
-                    eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l], x_in=xb[:rows])
+                    if OUT_OF_PLACE_START:
+                        eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l], x_in=xb[:rows])
+                    else:
+                        xb[(k + 1) * rows:(k + 2) * rows].copy_(xb[:rows])
+                        eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l])
                 eng.layers(xb[:(k + 1) * rows], (k + 1) * n, l, l + 1, [l] if l in removed_set else None)
                 if l in cand_set:
                     started.append(l)
-            eng.tail(xb[:rows], n, removed, labels=labels, correct=counts_dev[L:L + 1])
-            for k, c in enumerate(started):
-                eng.tail(xb[(k + 1) * rows:(k + 2) * rows], n, removed, labels=labels, correct=counts_dev[c:c + 1])
+            # the baseline (slot 0) and every candidate under way meet the same last block and classifier: ONE tail over all the
+            # slots (ssp2_tail_slots) instead of one per slot — the tail's launches on n CLS rows are latency-bound, thirteen
+            # of them per chunk were ~3 % of the step.  Slot s is counted in slot_counts[s] and added to its candidate's entry.
+            if TAIL_SLOTS and getattr(eng, "batch_lists", False):
+                slot_counts = torch.zeros(len(started) + 1, dtype=torch.int64, device=counts_dev.device)
+                eng.tail(xb[:(len(started) + 1) * rows], n, removed, labels=labels, correct=slot_counts, slots=len(started) + 1)
+                counts_dev.index_add_(0, _device_index([L] + started, counts_dev.device), slot_counts)
+            else:
+                eng.tail(xb[:rows], n, removed, labels=labels, correct=counts_dev[L:L + 1])
+                for k, c in enumerate(started):
+                    eng.tail(xb[(k + 1) * rows:(k + 2) * rows], n, removed, labels=labels, correct=counts_dev[c:c + 1])
             if (L - 1) in cand_set:
                 eng.tail(xb[:rows], n, removed + [L - 1], labels=labels, correct=counts_dev[L - 1:L])
             total += n

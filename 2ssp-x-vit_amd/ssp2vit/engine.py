@@ -248,19 +248,24 @@ class VitEngine:
 
     def tail(self, x: torch.Tensor, n: int, attn_skip: Optional[Sequence[int]] = None,
              labels: Optional[torch.Tensor] = None, correct: Optional[torch.Tensor] = None, want_logits: bool = False,
-             want_pred: bool = False):
+             want_pred: bool = False, slots: int = 1):
         """Last encoder block + head on the CLS rows only (x must hold the residual stream ENTERING the last block;
-        it is not modified).  Same results, bit for bit, as layers(x, depth-1, depth) + head(x)."""
-        logits = torch.empty(n, self.classes, dtype=torch.float32, device=self.device) if want_logits else None
-        pred = torch.empty(n, dtype=torch.int32, device=self.device) if want_pred else None
+        it is not modified).  Same results, bit for bit, as layers(x, depth-1, depth) + head(x).
+        `slots` > 1: x holds that many streams of n images side by side (ssp2_tail_slots); labels [n] are shared, `correct`
+        must have `slots` entries (slot s is counted in correct[s]), logits / pred cover slots * n images."""
+        tot = n * int(slots)
+        logits = torch.empty(tot, self.classes, dtype=torch.float32, device=self.device) if want_logits else None
+        pred = torch.empty(tot, dtype=torch.int32, device=self.device) if want_pred else None
         if labels is not None:
             labels = labels.to(self.device, torch.int64, non_blocking=True).contiguous()
             if correct is None:
-                correct = torch.zeros(1, dtype=torch.int64, device=self.device)
+                correct = torch.zeros(int(slots), dtype=torch.int64, device=self.device)
+            if correct.numel() < int(slots) or not correct.is_contiguous():
+                raise ValueError("`correct` needs one contiguous int64 entry per slot")
         skip_last = bool(self.absent[self.depth - 1]) or (attn_skip is not None and (self.depth - 1) in [int(i) for i in attn_skip])
         self._bind_stream()
-        check(self.lib.ssp2_tail(self.h, _ptr(x), n, int(skip_last), _ptr(logits), _ptr(pred), _ptr(labels),
-                                 _ptr(correct if labels is not None else None)))
+        check(self.lib.ssp2_tail_slots(self.h, _ptr(x), n, int(slots), int(skip_last), _ptr(logits), _ptr(pred), _ptr(labels),
+                                       _ptr(correct if labels is not None else None)))
         return logits, pred, correct
 
     def act_l2_accum(self, act: torch.Tensor, score_chain: str = "fp32") -> torch.Tensor:

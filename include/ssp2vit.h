@@ -157,6 +157,11 @@ int ssp2_head(ssp2_handle h, const float* x_dev, int n, int group, float* logits
  * attn_skip_last != 0 bypasses the last block's attention. */
 int ssp2_tail(ssp2_handle h, const float* x_dev, int n, int attn_skip_last, float* logits_dev, int32_t* pred_dev,
               const int64_t* labels_dev, int64_t* correct_dev);
+/* The same for `slots` residual streams of n_slot images each, side by side in x_dev (the baseline and the candidates of the
+ * layer-major depth search: they all meet the same last block and classifier): one launch sequence over slots * n_slot images.
+ * labels_dev [n_slot] is shared by the slots; correct_dev [slots] (int64, accumulated); logits_dev / pred_dev [slots * n_slot, ...]. */
+int ssp2_tail_slots(ssp2_handle h, const float* x_dev, int n_slot, int slots, int attn_skip_last, float* logits_dev, int32_t* pred_dev,
+                    const int64_t* labels_dev, int64_t* correct_dev);
 
 /* a8 on the device: keep only the listed FFN neurons of block `layer` — rows of fc1 (+bias) and
  * columns of fc2 are gathered in HBM (src/vit_pruning.py:297-311 does `W_int[keep]`, `B_int[keep]`, `W_out[:,keep]`

@@ -1402,3 +1402,27 @@ def test_out_of_place_block_input_equals_copy_then_in_place(gpu):
     assert float(a[pads].abs().max()) == 0.0 and float(b[pads].abs().max()) == 0.0       # pad rows zeroed (only they are cleared now)
     assert torch.equal(eng.forward_scores(parts, "pre_gelu", "fp32", 8), eng.forward_scores(cat, "pre_gelu", "fp32", 8))
     eng.close()
+
+
+def test_tail_over_all_slots_gives_the_per_slot_tails_integers_and_logits(gpu):
+    """ssp2_tail_slots (VitEngine.tail(slots=k)): the CLS-only last block + classifier over k residual streams laid side by side
+    — what the layer-major search ends with — against k separate tails: logits and predictions bit for bit, the same correct
+    count per slot (labels shared by the slots), with and without the last block's attention, k * n below and above the
+    persistent GEMM's 4096-row threshold for the K / V projection."""
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_base_patch16_224_d3", classes=10, seed=9, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
+    eng = VitEngine(w, max_images=5 * 24)
+    g = torch.Generator().manual_seed(6)
+    for n, k in ((3, 2), (24, 5)):
+        px = torch.randn(k * n, 3, 224, 224, generator=g).to(gpu)
+        x = eng.embed(px); eng.layers(x, k * n, 0, eng.depth - 1)
+        labels = torch.randint(0, 10, (n,), generator=g).to(gpu)
+        rows = n * eng.tokens
+        for skip in (None, [eng.depth - 1]):
+            lg, pr, cc = eng.tail(x, n, skip, labels=labels, want_logits=True, want_pred=True, slots=k)
+            for s_ in range(k):
+                l1, p1, c1 = eng.tail(x[s_ * rows:(s_ + 1) * rows], n, skip, labels=labels, want_logits=True, want_pred=True)
+                assert torch.equal(lg[s_ * n:(s_ + 1) * n], l1) and torch.equal(pr[s_ * n:(s_ + 1) * n], p1), (n, k, s_, skip)
+                assert int(cc[s_]) == int(c1[0]) == int((p1.long() == labels).sum())
+    eng.close()
