@@ -415,8 +415,16 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
         if counts_dev is None:
             counts_dev = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
         n = int(labels.size(0))
-        x = eng.embed(px)
-        if want_lm and eng.max_images >= slots * n:
+        lm = want_lm and eng.max_images >= slots * n
+        xb = None
+        if lm and getattr(eng, "batch_lists", False):
+            # the embedding lands straight in slot 0 of the slot buffer (round 2 embedded into its own tensor and copied it over)
+            rows0 = eng.rows(n)
+            xb = torch.empty(slots * rows0, eng.dim, dtype=torch.float32, device=eng.device)
+            x = eng.embed(px, x=xb[:rows0])
+        else:
+            x = eng.embed(px)
+        if lm:
             # Layer-major search: the baseline (slot 0) and the snapshots (the k-th candidate to start in slot k) sit
             # side by side in one buffer, and at block l the baseline and every candidate already under way (c < l) run
             # the block in ONE launch of (k + 1)*n images — same per-image arithmetic in the same order, l + 2 launches
@@ -425,8 +433,9 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
             # `removed` (earlier rounds of the iterative search) are bypassed for every slot alike.  Needs an engine
             # workspace for slots*n images.
             rows = x.shape[0]
-            xb = torch.empty(slots * rows, x.shape[1], dtype=x.dtype, device=x.device)
-            xb[:rows].copy_(x)
+            if xb is None:
+                xb = torch.empty(slots * rows, x.shape[1], dtype=x.dtype, device=x.device)
+                xb[:rows].copy_(x)
             started = []
             for l in range(L - 1):
                 k = len(started)
