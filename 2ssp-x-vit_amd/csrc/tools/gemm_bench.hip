@@ -1,6 +1,6 @@
 // Standalone micro-benchmark of gemm_bf16_kernel<EPI> on random bf16 data (HIP events, median of rounds).
 //   gemm_bench.bin M N K epi [iters] [tokens]       epi: 0 bf16, 1 resid, 2 fc1(+score), 3 patch, 4 f32 (128x128 kernel);
-//   10/11/12 bf16/resid/fc1 on the persistent 256x256 kernel, 20/21/22 the same on its round-1 version (A/B),
+//   10/11/12 bf16/resid/fc1 on the persistent 256x256 kernel (13/14: + pre- / post-GELU stage-1 score),
 //   15 resid + fused LayerNorm of the finished row panels (N = 768 / 1024 / 1280; x vs the 128x128 kernel, h vs layernorm_bf16_kernel),
 //   40/41/42 the same on the four-wave kernel (gemm256w4.hip.h), 30..33 e4m3 operands (gemm256 F8)
 #include <hip/hip_runtime.h>
@@ -13,7 +13,6 @@
 #include "../gemm256.hip.h"
 #include "../misc.hip.h"
 #include "gemm256w4.hip.h"
-#include "gemm256_v1.hip.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -67,13 +66,6 @@ template <int EPI, int SCORE = 0> static void launch256f8(GemmArgs g, hipStream_
   g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
   hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE, true>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(512), G256::LDS, s, g);
 }
-template <int EPI, int NW> static void launch256v1(GemmArgs g, hipStream_t s) {   // round-1 kernel, A/B reference
-  static bool done = false;
-  if (!done) { CK(hipFuncSetAttribute((const void*)gemm256v1_bf16_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, G256v1<NW>::LDS)); done = true; }
-  g.tiles_m = (g.M + 255) / 256; g.tiles_n = (g.N + 255) / 256;
-  hipLaunchKernelGGL((gemm256v1_bf16_kernel<EPI, NW>), dim3(std::min(g.tiles_m * g.tiles_n, nCU)), dim3(NW * 64), G256v1<NW>::LDS, s, g);
-}
-
 // epi 30 bf16-out (QKV), 31 resid (fc2), 32 fc1 (+GELU, e4m3 out), 33 fc1 + pre-GELU score (e4m3 out + slab): e4m3 operands.
 // Operands are quantised on the host (A: direct cast, W: per-row scale amax/448), the reference is the fp32 sum of the
 // exact products of the DEQUANTISED values, so the check isolates the kernel (layout, scale, epilogue) from quantisation.
@@ -179,8 +171,6 @@ int main(int argc, char** argv) {
                    case 10: launch256<EPI_BF16>(g, s); break; case 11: launch256<EPI_RESID>(g, s); break;
                    case 12: launch256<EPI_FC1>(g, s); break; case 13: launch256<EPI_FC1, 1>(g, s); break; case 14: launch256<EPI_FC1, 2>(g, s); break;
                    case 40: launch256w4<EPI_BF16>(g, s); break; case 41: launch256w4<EPI_RESID>(g, s); break; case 42: launch256w4<EPI_FC1>(g, s); break;
-                   case 20: launch256v1<EPI_BF16, 8>(g, s); break; case 21: launch256v1<EPI_RESID, 8>(g, s); break;
-                   case 22: launch256v1<EPI_FC1, 8>(g, s); break;
                    default: break; }
   };
   if (epi >= 10) {   // verify the large-tile kernel against the (oracle-validated) 128x128 kernel, bit for bit

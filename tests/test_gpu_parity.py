@@ -487,6 +487,16 @@ def test_cli_end_to_end_on_synthetic_vit_tiny(gpu, tmp_path):
     assert set(fw) == {"ffn", "heads", "qkv_dim"} and len(fw["ffn"]) == 12
     assert os.path.exists(os.path.join(rep["artifacts"]["pruned_model_dir"], "timm_model.pth"))
     assert any(f.startswith("report-") and f.endswith(".md") for f in os.listdir(out / "reports"))
+    mp = rep["mask_parity"]                                           # round 3: the cut-margin table of the masks just cut, in the report JSON
+    assert mp["blocks_total"] == 12 and mp["eps"] == 1e-3 and all(b["pruned"] == plan["per_block_neurons_to_prune"] for b in mp["blocks"])
+    assert json.load(open([os.path.join(out / "reports", f) for f in os.listdir(out / "reports") if f.endswith(".json")][0]))["mask_parity"]["blocks_total"] == 12
+    # round 3: --weights <local checkpoint> (the reference loads with from_pretrained / timm, auto_2ssp.py:636-667): the pruned
+    # model the first run saved (timm state dict: 12 blocks of reduced width, three of them without attention) is pruned AGAIN
+    rep2 = cli.main(["--weights", rep["artifacts"]["pruned_model_dir"], "--heads", "3", "--target", "0.2", "--eval-batches", "2",
+                     "--batch-size", "16", "--synthetic-calib", "32", "--min-remaining", "128", "--output-dir", str(tmp_path / "run2")])[0]
+    m2 = rep2["metrics"]
+    assert m2["params_before_stage1"] == m["params_after_stage2"] and m2["acc_baseline"] == 1.0
+    assert m2["params_after_stage2"] < m2["params_before_stage1"] and rep2["config"]["weights"] == rep["artifacts"]["pruned_model_dir"]
 
 
 def test_on_device_compaction_equals_engine_from_sliced_weights(gpu):
@@ -1425,4 +1435,18 @@ def test_tail_over_all_slots_gives_the_per_slot_tails_integers_and_logits(gpu):
                 l1, p1, c1 = eng.tail(x[s_ * rows:(s_ + 1) * rows], n, skip, labels=labels, want_logits=True, want_pred=True)
                 assert torch.equal(lg[s_ * n:(s_ + 1) * n], l1) and torch.equal(pr[s_ * n:(s_ + 1) * n], p1), (n, k, s_, skip)
                 assert int(cc[s_]) == int(c1[0]) == int((p1.long() == labels).sum())
+    eng.close()
+    # slots x n >= 4096 CLS rows (ViT-H/14's 32 slots x 320 images): the tail's projections on the CLS rows then take the persistent
+    # 256 x 256 GEMM — same bits as the 128 x 128 kernel the per-slot tails use (520 x 8 = 4160 images of the 5-token smoke geometry)
+    w, _, _ = load_tiny_golden("timm")
+    eng = _engine(w, 8 * 520)
+    n, k = 520, 8
+    px = torch.randn(k * n, 3, 32, 32, generator=g).to(gpu)
+    x = eng.embed(px); eng.layers(x, k * n, 0, eng.depth - 1)
+    labels = torch.randint(0, 10, (n,), generator=g).to(gpu)
+    lg, pr, cc = eng.tail(x, n, None, labels=labels, want_logits=True, want_pred=True, slots=k)
+    rows = n * eng.tokens
+    for s_ in (0, 3, 7):
+        l1, p1, c1 = eng.tail(x[s_ * rows:(s_ + 1) * rows], n, None, labels=labels, want_logits=True, want_pred=True)
+        assert torch.equal(lg[s_ * n:(s_ + 1) * n], l1) and torch.equal(pr[s_ * n:(s_ + 1) * n], p1) and int(cc[s_]) == int(c1[0])
     eng.close()
