@@ -333,7 +333,7 @@ __device__ unsigned long long* attn_stamp_ptr;    // [8 waves][256 slots] of wor
 template <int NT>
 __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                                int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
-                                                               int reverse = 0) {
+                                                               int reverse = 0, int stagger = 0) {
   static_assert(NT >= 1 && NT <= 7, "one consumer wave per query tile, wave 7 produces");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = 4, DT = 2, NKEY = NT * 32, KV = NKEY * 128, BUF = 2 * KV;
@@ -422,6 +422,11 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
     asm volatile("s_barrier" ::: "memory");
     ASTAMP(n * 4 + 1);                                       // B(i) passed
     if (!consumer) continue;
+    // STAGGER: waves 4..6 — the SIMD partners of waves 0..2 — start their tile `stagger` x 64 cycles late, so that their
+    // Q K^T MFMAs run beside the partner's softmax (VALU) instead of beside the partner's own Q K^T, and their softmax beside the
+    // partner's P V: two waves that run the same program from the same barrier otherwise meet on the same pipe in every phase
+    // (MI355X_MICROARCH.md "two waves per SIMD", item 9).  The delayed wave's idle time is its partner's uncontended time.
+    if (wave >= 4) for (int c = 0; c < stagger; ++c) __builtin_amdgcn_s_sleep(1);
 
     const char* Ks = smem + b * BUF;
     const char* Vs = Ks + KV;
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
 template <int NT>
 __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                             int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
-                                                            int reverse = 0) {
+                                                            int reverse = 0, int stagger = 0) {
   static_assert(NT >= 8 && NT <= 9, "waves 0..7 take tiles 0..7, wave 0 the ninth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DH = 80, KS = 5, DT = 3, CH = 10, NKEY = NT * 32, RSB = 160, KV = NKEY * RSB;     // 46080 B per operand
@@ -615,6 +620,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
     if (more) issue(it + G, 1, K0 + (b ^ 1) * KV);
     const char* Ks = K0 + b * KV;
     int head; const size_t r0 = row0_of(it, head);
+    if (wave >= 4) for (int c = 0; c < stagger; ++c) __builtin_amdgcn_s_sleep(1);      // see attn64_persist_kernel (STAGGER)
 
     // S^T = K Q^T and the softmax for the wave's tile(s); the score accumulators stay in registers across B2
     f32x16 sacc[NT];

@@ -323,7 +323,7 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
       hipLaunchKernelGGL((attn64_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
-                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev);
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER]);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -341,7 +341,7 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
       hipLaunchKernelGGL((attn80_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
-                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev);
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER]);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -408,6 +408,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
     e->opt[SSP2_OPT_FC1_BIG_TILES] = getenv("SSP2_FC1_SMALL_TILES") ? 0 : 1;
     e->opt[SSP2_OPT_GROUP256] = env_int("SSP2_GROUP256", 0);
     e->opt[SSP2_OPT_PATCH_LDS] = env_int("SSP2_PATCH_LDS", 1);
+    e->opt[SSP2_OPT_ATTN_STAGGER] = env_int("SSP2_ATTN_STAGGER", 0);
   }
   e->d_int.assign(d.d_int, d.d_int + d.depth);
   e->d.d_int = e->d_int.data();
