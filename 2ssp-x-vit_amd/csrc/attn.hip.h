@@ -16,6 +16,8 @@
 #include <type_traits>
 #include "common.hip.h"
 
+#define ATTN_OUT8_SCALE 16.0f        // fp8 mode: attention outputs are written as e4m3(o * 16); the out-projection multiplies by 1 / 16
+
 // CLS_ONLY (evaluation tail): only query 0 of every image is needed.  q then comes from a compact [n, dim] buffer
 // (q_img_stride = dim, q_ld = 0: the whole 32-query tile reads the CLS row) and only row 0 is stored, into a compact
 // [n, dim] output.  The arithmetic for query 0 is the same instruction sequence as in the full kernel, so the tail
@@ -333,7 +335,10 @@ __device__ unsigned long long* attn_stamp_ptr;    // [8 waves][256 slots] of wor
 template <int NT>
 __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                                int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
-                                                               int reverse = 0, int stagger = 0) {
+                                                               int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0) {
+  // out8 (fp8 mode, round 3): the output is ALSO the A operand of an e4m3 out-projection — written as e4m3(o * ATTN_OUT8_SCALE)
+  // bytes [rows, ldo8] instead of bf16 (a fixed power-of-two scale: an attention output is a convex combination of V rows, O(0.1-1);
+  // x 16 puts it into the upper half of the e4m3 range, the projection's epilogue divides it out exactly)
   static_assert(NT >= 1 && NT <= 7, "one consumer wave per query tile, wave 7 produces");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = 4, DT = 2, NKEY = NT * 32, KV = NKEY * 128, BUF = 2 * KV;
@@ -510,6 +515,29 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
     asm volatile("" : "+v"(oacc[0]), "+v"(oacc[1]));
     ASTAMP(n * 4 + 3);                                       // P V done, Q of the next item here
 #endif
+    if (out8) {
+      // e4m3 bytes: the wave's [32 queries][64 B] tile through its staging area (a lane's four consecutive d_h are one dword), then
+      // 128 sixteen-byte row chunks, two per lane
+      const float sc8 = inv * ATTN_OUT8_SCALE;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *(uint32_t*)(ost + l31 * 64 + dt * 32 + 8 * g4 + 4 * lh) = pack_e4m3x4_from(oacc[dt][4 * g4] * sc8, oacc[dt][4 * g4 + 1] * sc8,
+                                                                                    oacc[dt][4 * g4 + 2] * sc8, oacc[dt][4 * g4 + 3] * sc8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      f32x4 o8[2];
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) o8[r2] = *(const f32x4*)(ost + (r2 * 64 + lane) * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      int head8; const size_t r08 = row0_of(it, head8);
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2) {
+        const int c = r2 * 64 + lane, qq = wave * 32 + (c >> 2);
+        if (qq < tokens) *(f32x4*)(out8 + (r08 + qq) * (size_t)ldo8 + head8 * 64 + (c & 3) * 16) = o8[r2];
+      }
+      continue;
+    }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -553,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
 template <int NT>
 __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                             int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
-                                                            int reverse = 0, int stagger = 0) {
+                                                            int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0) {
   static_assert(NT >= 8 && NT <= 9, "waves 0..7 take tiles 0..7, wave 0 the ninth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DH = 80, KS = 5, DT = 3, CH = 10, NKEY = NT * 32, RSB = 160, KV = NKEY * RSB;     // 46080 B per operand
@@ -691,16 +719,22 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
       const int q = qt * 32 + l31;
       if (q < tokens) {
         bf16* op = out + (r0 + q) * ldo + head * DH;
+        uint8_t* op8 = out8 ? out8 + (r0 + q) * (size_t)ldo8 + head * DH : nullptr;       // fp8 mode: e4m3(o * 16) bytes (see attn64_persist_kernel)
+        const float sc8 = inv * ATTN_OUT8_SCALE;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const int d0 = dt * 32 + 8 * g4 + 4 * lh;
             if (d0 < DH) {
-              bf16x4 o4;
+              if (op8) {
+                *(uint32_t*)(op8 + d0) = pack_e4m3x4_from(oacc[dt][4 * g4] * sc8, oacc[dt][4 * g4 + 1] * sc8, oacc[dt][4 * g4 + 2] * sc8, oacc[dt][4 * g4 + 3] * sc8);
+              } else {
+                bf16x4 o4;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) o4[j] = (bf16)(oacc[dt][4 * g4 + j] * inv);
-              *(bf16x4*)(op + d0) = o4;
+                for (int j = 0; j < 4; ++j) o4[j] = (bf16)(oacc[dt][4 * g4 + j] * inv);
+                *(bf16x4*)(op + d0) = o4;
+              }
             }
           }
       }

@@ -117,6 +117,7 @@ struct ssp2_engine {
   bool fp8 = false;             // ssp2_set_precision(SSP2_PREC_FP8): QKV / fc1 / fc2 of launches with >= 4096 rows on e4m3 MFMA
   uint8_t *hbuf8 = nullptr, *act8 = nullptr;   // LayerNorm output / FFN activation as e4m3 bytes
   float* hscale = nullptr;                     // per-row activation scale of hbuf8 (amax / 448, written by the LayerNorm)
+  uint8_t* obuf8 = nullptr;                    // attention output as e4m3(o * 16) bytes: the A operand of the fp8 out-projection (SSP2_OPT_FP8_PROJ)
   int ld8_dim = 0, ld8_int_max = 0;
   float* stage_f32 = nullptr;   // staging buffer of ssp2_load_tensor (host sources)
   size_t stage_cap = 0;
@@ -295,7 +296,7 @@ static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const flo
 }
 
 template <int DH, int NT, bool CLS>
-static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
+static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullptr) {
   // d_h = 64: 128-byte K and V rows (LDS-DMA staging) + 4 KiB per wave of output staging; else padded rows
   // d_h = 80 with a whole number of 1-KiB DMA pieces: 160-byte rows + 64 bytes of slack behind V (attn.hip.h)
   constexpr int smem = DH == 64 ? NT * 32 * 256 + 4 * 4096
@@ -323,7 +324,7 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
       hipLaunchKernelGGL((attn64_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
-                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER]);
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -341,11 +342,12 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
       hipLaunchKernelGGL((attn80_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
-                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER]);
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim);
       HIPCHK(hipGetLastError());
       return 0;
     }
   }
+  if (out8) return fail(SSP2_ESTATE, "e4m3 attention output needs a persistent attention kernel (d_h = 64 / 80, SSP2_OPT_ATTN_PERSIST)");
   if (CLS)   // q from the compact CLS projection, only row 0 kept, compact [n, D] output
     hipLaunchKernelGGL((attn_fwd_kernel<DH, NT, true>), dim3(e->d.heads, n), dim3(256), smem, e->stream, e->qkvbuf, ld, e->q_cls,
                        (size_t)D, 0, e->o_cls, (size_t)D, D, e->tokens, D, 1.0f / sqrtf((float)DH), rm);
@@ -356,9 +358,14 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm) {
   return 0;
 }
 
-static int launch_attn(ssp2_engine* e, int n, RowMap rm, bool cls_only = false) {
+// which geometries have a persistent kernel (the ones that can write the e4m3 output)
+static bool attn_persistent(const ssp2_engine* e) {
   const int nt = (e->tokens + 31) / 32;
-#define ATTN_CASE(DH_, NT_) if (e->dh == DH_ && nt == NT_) return cls_only ? launch_attn_t<DH_, NT_, true>(e, n, rm) : launch_attn_t<DH_, NT_, false>(e, n, rm)
+  return e->opt[SSP2_OPT_ATTN_PERSIST] && ((e->dh == 64 && nt >= 4 && nt <= 7) || (e->dh == 80 && nt >= 8 && nt <= 9));
+}
+static int launch_attn(ssp2_engine* e, int n, RowMap rm, bool cls_only = false, uint8_t* out8 = nullptr) {
+  const int nt = (e->tokens + 31) / 32;
+#define ATTN_CASE(DH_, NT_) if (e->dh == DH_ && nt == NT_) return cls_only ? launch_attn_t<DH_, NT_, true>(e, n, rm) : launch_attn_t<DH_, NT_, false>(e, n, rm, out8)
   ATTN_CASE(64, 7);   // 224/16: 197 tokens (Ti/S/B/L)
   ATTN_CASE(80, 9);   // 224/14: 257 tokens (H/14)
   ATTN_CASE(16, 1);   // reference smoke config: 32/16, 5 tokens
@@ -409,6 +416,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
     e->opt[SSP2_OPT_GROUP256] = env_int("SSP2_GROUP256", 0);
     e->opt[SSP2_OPT_PATCH_LDS] = env_int("SSP2_PATCH_LDS", 1);
     e->opt[SSP2_OPT_ATTN_STAGGER] = env_int("SSP2_ATTN_STAGGER", 0);
+    e->opt[SSP2_OPT_FP8_PROJ] = env_int("SSP2_FP8_PROJ", 1);
   }
   e->d_int.assign(d.d_int, d.d_int + d.depth);
   e->d.d_int = e->d_int.data();
@@ -635,6 +643,7 @@ int ssp2_set_precision(ssp2_handle e, int mode) {
     Layer& L = e->layers[l];
     if (!(L.qkv.w_set && L.fc1.w_set && L.fc2.w_set)) return fail(SSP2_ESTATE, "set_precision(fp8): layer %d weights not loaded yet", l);
     if ((rc = quantise_mat(e, L.qkv)) || (rc = quantise_mat(e, L.fc1)) || (rc = quantise_mat(e, L.fc2))) return rc;
+    if (L.proj.w_set && (rc = quantise_mat(e, L.proj))) return rc;       // the e4m3 out-projection (SSP2_OPT_FP8_PROJ)
   }
   if (!e->hbuf8) {
     e->ld8_dim = ceil_to(e->d.dim, 128);
@@ -642,6 +651,7 @@ int ssp2_set_precision(ssp2_handle e, int mode) {
     if ((rc = dalloc(e, &e->hbuf8, (size_t)e->rows_cap * e->ld8_dim, true))) return rc;
     if ((rc = dalloc(e, &e->act8, (size_t)e->rows_cap * e->ld8_int_max, true))) return rc;
     if ((rc = dalloc(e, &e->hscale, (size_t)e->rows_cap, true))) return rc;
+    if ((rc = dalloc(e, &e->obuf8, (size_t)e->rows_cap * e->ld8_dim, true))) return rc;
   }
   e->fp8 = true;
   return 0;
@@ -759,15 +769,24 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
         if ((rc = launch_gemm<EPI_BF16>(e, q, SSP2_K_GEMM_QKV))) return rc;
       }
       h_ready = false;
-      if ((rc = launch_attn(e, n, rm))) return rc;
+      // fp8 out-projection (SSP2_OPT_FP8_PROJ): the persistent attention kernel writes e4m3(o * 16) bytes, the projection runs on
+      // e4m3 operands and divides the 16 out in its epilogue
+      const bool f8_proj = f8 && e->opt[SSP2_OPT_FP8_PROJ] && attn_persistent(e) && L.proj.w8 && D % 64 == 0;
+      if ((rc = launch_attn(e, n, rm, false, f8_proj ? e->obuf8 : nullptr))) return rc;
       GemmArgs p{};
-      p.A = e->obuf; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.bias = L.proj.b;
-      p.M = M; p.N = D; p.K = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = x; p.ldx = D; p.xin = xsrc;
-      if (const int lnv = ln_fusable(e, M, D, false)) {          // + LN2 of this layer: fc1's operand
+      p.bias = L.proj.b;
+      p.M = M; p.N = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = x; p.ldx = D; p.xin = xsrc;
+      if (f8_proj) {
+        p.A = (const bf16*)e->obuf8; p.lda = e->ld8_dim; p.W = (const bf16*)L.proj.w8; p.ldw = L.proj.ld8; p.K = e->ld8_dim; p.wscale = L.proj.wscale;
+        p.ascale_const = 1.0f / ATTN_OUT8_SCALE;
+      } else {
+        p.A = e->obuf; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.K = D;
+      }
+      if (const int lnv = ln_fusable(e, M, D, f8_proj)) {        // + LN2 of this layer: fc1's operand
         set_ln(p, L.ln2_g, L.ln2_b, f8_fc1);
-        if ((rc = launch_resid_ln<false>(e, p, lnv, SSP2_K_GEMM_PROJ))) return rc;
+        if ((rc = f8_proj ? launch_resid_ln<true>(e, p, lnv, SSP2_K_GEMM_PROJ) : launch_resid_ln<false>(e, p, lnv, SSP2_K_GEMM_PROJ))) return rc;
         h_ready = true;
-      } else if ((rc = launch_gemm<EPI_RESID>(e, p, SSP2_K_GEMM_PROJ))) return rc;
+      } else if ((rc = f8_proj ? launch_gemm256<EPI_RESID, 0, true>(e, p, SSP2_K_GEMM_PROJ) : launch_gemm<EPI_RESID>(e, p, SSP2_K_GEMM_PROJ))) return rc;
       xsrc = x;
     }
     const int ld8_int = ceil_to(L.ld_int, 128);

@@ -59,6 +59,7 @@ struct GemmArgs {
   // EPI_FC1 then writes e4m3 bytes to `out` (ldo in bytes) for the fp8 fc2 that follows
   const float* wscale;
   const float* ascale;        // fp8: per-ROW dequantisation scale of the A operand ([M], written by the LayerNorm that produced it) or nullptr (= 1)
+  float ascale_const;         // fp8, ascale == nullptr: one dequantisation scale for the whole A operand (0 = 1; the e4m3 attention output: 1 / 16)
   // LayerNorm fused behind the residual epilogue (gemm256 kernel, EPI_RESID with SCORE = N / 256 only): once a workgroup has
   // written all N / 256 column tiles of a 256-row panel of x it normalises those rows (gamma / beta fp32 [N], eps) into
   // ln_out (bf16, ld ln_ld elements) or, fp8 mode, ln_out8 (e4m3 bytes, ld ln_ld bytes) — the operand of the next projection

@@ -141,6 +141,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       if (g.ascale) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) { int r = m0_ + wm * 128 + a * 32 + l31; r = r < g.M ? r : g.M - 1; asc_next[a] = g.ascale[r]; }
+      } else if (g.ascale_const != 0.f) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) asc_next[a] = g.ascale_const;
       }
     }
   };
