@@ -117,6 +117,10 @@ struct ssp2_engine {
   bool fp8 = false;             // ssp2_set_precision(SSP2_PREC_FP8): QKV / fc1 / fc2 of launches with >= 4096 rows on e4m3 MFMA
   uint8_t *hbuf8 = nullptr, *act8 = nullptr;   // LayerNorm output / FFN activation as e4m3 bytes
   float* hscale = nullptr;                     // per-row activation scale of hbuf8 (amax / 448, written by the LayerNorm)
+  unsigned int* ln_sync = nullptr;             // fused LayerNorm: queue heads + panel arrival counters (GemmArgs.ln_sync)
+  int ln_set = 0;                              // queue-head set of the next fused launch (the launch zeroes the other one)
+  int n_xcc_seen = 0;
+  bool xcc_ok = false;                         // XCC_ID probe at create: ids 0..7 seen, nothing else (else the fused form stays off)
   uint8_t* obuf8 = nullptr;                    // attention output as e4m3(o * 16) bytes: the A operand of the fp8 out-projection (SSP2_OPT_FP8_PROJ)
   int ld8_dim = 0, ld8_int_max = 0;
   float* stage_f32 = nullptr;   // staging buffer of ssp2_load_tensor (host sources)
@@ -202,9 +206,9 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
     attr_done[e->dev] = true;
   }
   if (!(EPI == EPI_RESID && SCORE > 0)) g.reverse = next_dir(e);
+  else { g.ln_sync = e->ln_sync; g.ln_set = e->ln_set; e->ln_set ^= 1; }      // LayerNorm behind the epilogue: per-XCD tile queues
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
-  // EPI_RESID with SCORE > 0 = LayerNorm fused behind the epilogue: one workgroup per ROW PANEL (it owns all its column tiles)
-  const int wgs = (EPI == EPI_RESID && SCORE > 0) ? std::min(g.tiles_m, e->n_cu) : std::min(g.tiles_m * g.tiles_n, e->n_cu);
+  const int wgs = std::min(g.tiles_m * g.tiles_n, e->n_cu);
   hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE, F8>), dim3(wgs), dim3(512), G256::LDS, e->stream, g);
   HIPCHK(hipGetLastError());
   return 0;
@@ -212,31 +216,30 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
 
 // The residual projections (attention out-proj, fc2) can normalise the rows they finish — the LayerNorm that feeds the
 // NEXT projection — inside the GEMM kernel (gemm256.hip.h, LNV): the standalone kernel (4.5 KB per row through HBM, 9 % of
-// the step) then does not run.  OPT-IN (SSP2_LN_FUSION=1), because it does not pay as built (profiles/r02_d_gemm_ln_fusion.txt):
-// a workgroup must own whole 256-row panels, i.e. walk a panel's dim / 256 column tiles one after the other, and so reads
-// its A panel that many times from the Infinity Cache / HBM instead of sharing it through the XCD's L2 with the workgroups
-// that take the other column tiles at the same time (32 x 393 KB per XCD do not stay in 4 MiB): out-proj 117 -> 145 us,
-// fc2 334 -> 391 us for 63040 rows, and the phase itself is VALU-bound at ~25 us per panel (180 instructions per row, two
-// waves per SIMD) against 50-60 us for the standalone launch — out-proj + LN 177 -> 170 us, fc2 + LN 394 -> 416 us.
+// the step) then does not run for that LayerNorm.  OPT-IN (SSP2_LN_FUSION=1 / ssp2_set_option; 2 = the same, kept for the tests
+// that ask for "always"), because neither form built so far pays:
+//   round 2  one workgroup owns a whole 256-row panel and walks its dim / 256 column tiles one after the other: the A panel is
+//            read that many times from the Infinity Cache (profiles/r02_d_gemm_ln_fusion.txt);
+//   round 3  VERDICT r02's form: plain tile order, per-XCD work queues keyed on the hardware's XCC_ID, and the panel's
+//            LAST-ARRIVING workgroup normalises it — no spin-wait, no extra barrier, one returning atomic per tile hidden behind
+//            the epilogue.  The scheduling is free (queues + arrivals without the LayerNorm phase time like the plain kernel,
+//            +-1 %), and the phase costs EXACTLY what the standalone launch costs: 499 us for 630 400 rows inside out-proj
+//            against 490 us alone, 257 against 245 us for 315 200 rows inside fc2 (profiles/r03_q_ln_fusion_last_arriver.txt) —
+//            with two, four or eight rows in flight per wave and with the rows' dependent chains interleaved in pairs alike.
+//            The panel's rows are not in the L2 any more when its last tile is done (the XCD's 32 CUs write 8 MB per tile round
+//            into 4 MB), so the phase reads them back through the same saturated memory system as the standalone kernel, from a
+//            CU whose matrix pipe idles meanwhile: the same bytes at the same 5.7 TB/s, now on the GEMM's critical path.  Step
+//            A/B: +0.6 % (slower).  A fusion that pays would have to keep the finished rows ON the CU (registers / LDS) until the
+//            whole row exists — a 256 x dim fp32 panel per workgroup, which the 256 x 256 tile's accumulators leave no room for.
 // Results are bit-identical either way (one row routine, ln_row_finish; tests/test_gpu_parity.py).
-// Conditions when switched on: the launch goes to the 256 x 256 kernel, dim = 3, 4 or 5 column tiles, and a cost model in
-// cycles says the fused form is the cheaper one.  Returns dim / 256 or 0.
+// Conditions when switched on: the launch goes to the 256 x 256 kernel, dim = 3, 4 or 5 column tiles, at least two K-tiles per
+// tile (the tile stream), and the XCC_ID probe at create saw nothing but ids 0..7.  Returns dim / 256 or 0.
 static int ln_fusable(const ssp2_engine* e, int M, int K, bool f8) {
   const int D = e->d.dim;
   const int on = e->opt[SSP2_OPT_LN_FUSION];
-  if (!on || M < kBigTileMinRows || D % 256 || D / 256 < 3 || D / 256 > 5 || !e->opt[SSP2_OPT_BIG_TILES]) return 0;
-  if (on == 2) return D / 256;               // 2: always (tests: both residual projections of every layer)
-  const int tn = D / 256, tm = (M + 255) / 256, cu = e->n_cu;
-  const int rounds_fused = (tm + cu - 1) / cu * tn, rounds_plain = (tm * tn + cu - 1) / cu;
-  // cycles (≈1.86 GHz): a K-tile of the main loop 2.6 k (fp8: K-tiles of 128), tile change 9 k; the A panel's tn - 1 extra
-  // reads at ~8 TB/s from the Infinity Cache when A fits there, ~5 TB/s otherwise, half of it hidden; LayerNorm: standalone
-  // 4.5 KB per row at 5 TB/s, fused ≈ 46 k (25 us) per panel of 256 rows
-  const double tile_cyc = (double)(K / (f8 ? 128 : 64)) * 2600.0 + 9000.0;
-  const double a_bytes = (double)M * K * (f8 ? 1 : 2);
-  const double reread = 0.5 * (tn - 1) * a_bytes / (a_bytes < 200e6 ? 8e12 : 5e12) * 1.86e9;
-  const double ln_alone = (double)M * 4608.0 / 5.0e12 * 1.86e9 + 6000.0;
-  const double ln_fused = (double)((tm + cu - 1) / cu) * 46000.0 + reread;
-  return (rounds_fused - rounds_plain) * tile_cyc + ln_fused < ln_alone ? tn : 0;
+  if (!on || !e->xcc_ok || M < kBigTileMinRows || D % 256 || D / 256 < 3 || D / 256 > 5 || !e->opt[SSP2_OPT_BIG_TILES]) return 0;
+  if (K / (f8 ? 128 : 64) < 2) return 0;
+  return D / 256;
 }
 template <bool F8>
 static int launch_resid_ln(ssp2_engine* e, const GemmArgs& g, int lnv, int klass) {
@@ -470,7 +473,23 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
   TRY(dalloc(e, &e->h_cls, (size_t)d.max_images * d.dim, true));
   TRY(dalloc(e, &e->act_cls, (size_t)d.max_images * e->ld_int_max, true));
   TRY(dalloc(e, &e->logits, (size_t)d.max_images * d.classes, true));
+  TRY(dalloc(e, &e->ln_sync, (size_t)16 + (M + 255) / 256 + 1, true));
 #undef TRY
+  {   // the fused LayerNorm trusts the hardware's XCC_ID to name the L2 a workgroup sits behind: look at what it reports once
+    unsigned int* ids = nullptr;
+    const int nb = e->n_cu > 0 ? 4 * e->n_cu : 1024;
+    if (hipMalloc((void**)&ids, nb * sizeof(unsigned int)) == hipSuccess) {
+      std::vector<unsigned int> h(nb, 0xffffffffu);
+      hipLaunchKernelGGL(xcc_probe_kernel, dim3(nb), dim3(64), 0, e->stream, ids);
+      if (hipStreamSynchronize(e->stream) == hipSuccess && hipMemcpy(h.data(), ids, nb * sizeof(unsigned int), hipMemcpyDeviceToHost) == hipSuccess) {
+        unsigned seen = 0; bool bad = false;
+        for (unsigned v : h) { if (v > 7) bad = true; else seen |= 1u << v; }
+        e->xcc_ok = !bad && seen != 0;
+        e->n_xcc_seen = __builtin_popcount(seen);
+      }
+      hipFree(ids);
+    }
+  }
   *out = e;
   return 0;
 }
@@ -744,7 +763,6 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
   // x_in: the residual stream ENTERING block l_begin is read from there (LayerNorm input and the first residual add), everything
   // from the first residual add on lives in x — out of place for one residual epilogue, no copy of the stream
   const float* xsrc = (x_in && x_in != x) ? x_in : x;
-  if (xsrc != x && e->opt[SSP2_OPT_LN_FUSION]) return fail(SSP2_EINVAL, "ssp2_layers_from: out-of-place input with the fused LayerNorm is not supported");
   auto set_ln = [&](GemmArgs& a, const float* gm, const float* bt, bool to_fp8) {
     a.ln_g = gm; a.ln_b = bt; a.ln_eps = e->d.ln_eps;
     if (to_fp8) { a.ln_out8 = e->hbuf8; a.ln_ld = e->ld8_dim; a.ln_ascale = e->hscale; } else { a.ln_out = e->hbuf; a.ln_ld = D; }

@@ -60,11 +60,14 @@ struct GemmArgs {
   const float* wscale;
   const float* ascale;        // fp8: per-ROW dequantisation scale of the A operand ([M], written by the LayerNorm that produced it) or nullptr (= 1)
   float ascale_const;         // fp8, ascale == nullptr: one dequantisation scale for the whole A operand (0 = 1; the e4m3 attention output: 1 / 16)
-  // LayerNorm fused behind the residual epilogue (gemm256 kernel, EPI_RESID with SCORE = N / 256 only): once a workgroup has
-  // written all N / 256 column tiles of a 256-row panel of x it normalises those rows (gamma / beta fp32 [N], eps) into
+  // LayerNorm fused behind the residual epilogue (gemm256 kernel, EPI_RESID with SCORE = N / 256 only): the workgroup that
+  // writes the LAST of the N / 256 column tiles of a 256-row panel of x normalises those rows (gamma / beta fp32 [N], eps) into
   // ln_out (bf16, ld ln_ld elements) or, fp8 mode, ln_out8 (e4m3 bytes, ld ln_ld bytes) — the operand of the next projection
   const float* ln_g; const float* ln_b; bf16* ln_out; uint8_t* ln_out8; int ln_ld; float ln_eps;
   float* ln_ascale;           // with ln_out8: the rows' activation scales ([M]) the fused phase writes beside the e4m3 bytes
+  // ... scheduling state of that form (see gemm256.hip.h, LNV): [0..15] two sets of 8 per-XCD tile-queue counters (a launch
+  // uses set ln_set and zeroes the other one for the next fused launch), [16 + p] arrival counter of row panel p (left at 0)
+  unsigned int* ln_sync; int ln_set;
 #ifdef GEMM_STAMPS
   unsigned long long* stamps; // diagnostic build only: [blocks][64] s_memtime values of wave 0
 #endif

@@ -201,10 +201,136 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   // nothing on the matrix pipe); riding behind MFMAs they cost ~50 cycles each of a COMPUTE phase.
   const bool stream = nk >= 2;
   int sa = C::A0, sb = C::B0;            // ring slots of the K-tile about to be read (persist across tiles)
-  // Tile walk.  Plain: tiles wg, wg + G, ... of the N-fastest numbering.  LNV: a workgroup owns whole ROW PANELS
-  // (wg, wg + G, ...) and takes a panel's tiles_n column tiles back to back — the same numbering, another successor.
-  int tile = LNV ? wg * g.tiles_n : wg;
-  auto next_of = [&](int t) { return LNV ? ((t + 1) % g.tiles_n ? t + 1 : t + 1 + (G - 1) * g.tiles_n) : t + G; };
+  // Tile walk.  Plain: tiles wg, wg + G, ... of the N-fastest numbering.
+  // LNV (LayerNorm behind the residual epilogue): the panel's LAST-ARRIVING workgroup normalises it, so (1) the tiles_n column
+  // tiles of a panel run at the same time on different CUs and share the A panel through the L2, as in the plain order (round 2's
+  // form made ONE workgroup own the whole panel and read its A panel tiles_n times), and (2) the rows it reads were written by
+  // other CUs — they are coherent in the L2 of ONE XCD only.  Hence a work queue per XCD, keyed on the hardware's XCC_ID
+  // (not on the blockIdx -> XCD convention xcd_remap assumes for speed): XCD x owns panels x, x + 8, ...; queue position p is
+  // column tile p % tiles_n of its (p / tiles_n)-th panel, claimed with one atomic add per tile.  Claims run two tiles ahead (the
+  // next tile's first K-tiles ride on this tile's last two, so its id must be known a whole tile early); every claim and every
+  // arrival is ONE returning atomic of wave 4 issued at the start of an epilogue and read at its end — no spin, no extra
+  // barrier anywhere: a workgroup learns at the top of tile t + 2 whether its tile t completed a panel.
+  int tile = wg, lnq_next = ntiles, lnq_slot = 0, lnq_prev_panel = -1, lnq_cnt = 0, lnq_claimed = 0;
+  uint32_t lnq_res = 0;                // wave 4: lane 0 the claimed queue position, lane 1 the panel's arrivals before ours
+  int xcc = 0;
+  unsigned int* const lnq_queue = LNV ? g.ln_sync + g.ln_set * 8 : nullptr;
+  auto pos_tile = [&](int p) { const int pl = p / g.tiles_n, panel = xcc + 8 * pl; return panel < g.tiles_m ? panel * g.tiles_n + (p - pl * g.tiles_n) : ntiles; };
+  if constexpr (LNV > 0) {
+    uint32_t r;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(r));
+    xcc = r & 7;
+    if (blockIdx.x == 0 && tid < 8) g.ln_sync[(g.ln_set ^ 1) * 8 + tid] = 0;      // the NEXT fused launch's queue heads
+    if (tid == 256) *(volatile uint32_t*)(smem + C::A2) = atomicAdd(lnq_queue + xcc, 2u);    // A2: the first DMAs go to B0, A0, A1
+    __syncthreads();
+    const int p0 = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)(smem + C::A2));
+    __syncthreads();
+    tile = pos_tile(p0); lnq_next = pos_tile(p0 + 1);
+  }
+  auto next_of = [&](int t) { return LNV ? lnq_next : t + G; };
+  // LayerNorm of a finished 256-row panel (every wave of the workgroup calls it at the same point; no barrier, no LDS inside).
+  // All tiles_n column tiles of the panel have arrived — their stores were acknowledged by this XCD's L2 before the arrivals
+  // were counted — so the rows are read with device-scope loads (sc1: past the CU's vector L1, which may hold this
+  // workgroup's own, older, view of its column range).  Wave w normalises rows w, w + 8, ... exactly as
+  // layernorm_bf16_kernel does (one wave per row, ln_row_finish).  The standalone kernel moves 4.5 KB per row through HBM;
+  // here the reads are L2 hits and only the bf16 / e4m3 rows leave.
+  auto ln_phase = [&](int panel) __attribute__((always_inline)) {
+    if constexpr (LNV > 0) {
+#ifdef GEMM_ABL_NOLN   // ablation (timing builds of tools/gemm_bench only): queues and arrivals as usual, the rows are not normalised
+      if (tid == 0) g.ln_sync[16 + panel] = 0;
+      return;
+#endif
+      const int pm0 = panel * C::BM;
+      int ll = lane;
+      asm volatile("" : "+v"(ll));                 // opaque: nothing below may be hoisted over a main loop (registers)
+      if (tid == 0) g.ln_sync[16 + panel] = 0;      // the arrival counter is left at zero for the next launch
+      const int nv = g.N >> 2;
+      f32x4 g4[LNV > 0 ? LNV : 1], b4[LNV > 0 ? LNV : 1];
+#pragma unroll
+      for (int i = 0; i < LNV; ++i) {
+        g4[i] = ((const f32x4*)g.ln_g)[i * 64 + ll]; b4[i] = ((const f32x4*)g.ln_b)[i * 64 + ll];     // N = 256 * LNV: every chunk exists
+      }
+      const int rows_here = g.M - pm0 < C::BM ? g.M - pm0 : C::BM;
+      const float inv_d = 1.0f / (float)g.N;
+      // wave w: rows w, w + 8, ... (32 of them), two register sets in ping-pong: the loads of row i + 1 are in flight
+      // while row i is normalised.  The loads are inline asm with a counted wait of our own (as for the LDS-DMA): left to
+      // hipcc, every row waited with vmcnt(0) — for its own loads AND the previous row's stores, 1.9 us per row.
+      const uint32_t ll16 = (uint32_t)ll * 16;
+      auto load_row = [&](f32x4 (&dst)[LNV > 0 ? LNV : 1], int i) __attribute__((always_inline)) {
+        int r = wave + 8 * i;
+        r = r < rows_here ? r : rows_here - 1;
+        const char* xr = (const char*)(g.x + (size_t)(pm0 + r) * g.ldx);
+#pragma unroll
+        for (int c = 0; c < LNV; ++c)
+          // s_nop 4: the SGPR base may come straight out of a v_readlane_b32 (hipcc reloads spilled scalars that way), and a
+          // vector-memory instruction that reads an SGPR a VALU instruction wrote needs five wait states in between — which hipcc
+          // pads for instructions it knows, not for inline asm.  (Found the hard way: without it ~30 of 82 240 rows of a dim-1280
+          // launch were normalised from another row's chunk, always a wave's SECOND row: the one whose address was a spill reload.)
+          asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=&v"(dst[c]) : "v"(ll16), "s"(xr + c * 1024) : "memory");
+      };
+      // a counted wait that the row registers pass through (no use moves above it): all but the N youngest vector-memory
+      // operations have landed
+      // a counted wait that TWO rows' registers pass through (no use moves above it): all but the N youngest vector-memory
+      // operations have landed
+      auto landed2 = [&](f32x4 (&d)[LNV > 0 ? LNV : 1], f32x4 (&e)[LNV > 0 ? LNV : 1], auto n_c) __attribute__((always_inline)) {
+        constexpr int N = decltype(n_c)::value;
+        if constexpr (LNV == 3) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]) : "n"(N) : "memory");
+        if constexpr (LNV == 4) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]) : "n"(N) : "memory");
+        if constexpr (LNV == 5) asm volatile("s_waitcnt vmcnt(%10)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]) : "n"(N) : "memory");
+      };
+      auto rows = [&](auto out8_c) __attribute__((always_inline)) {
+        constexpr bool OUT8 = decltype(out8_c)::value;
+        // rows past the panel's end (last panel only) are clamped to its last row for the load AND the store: the same
+        // bits land on the same address again, and every row costs at least LNV loads + LNV stores — the counts below
+        auto finish = [&](const f32x4 (&src)[LNV > 0 ? LNV : 1], int i) __attribute__((always_inline)) {
+          int r = wave + 8 * i;
+          r = r < rows_here ? r : rows_here - 1;
+          const size_t ro = (size_t)(pm0 + r) * g.ln_ld;
+          ln_row_finish<LNV, true, OUT8>(src, ll, nv, inv_d, g.ln_eps, g4, b4, OUT8 ? (void*)(g.ln_out8 + ro) : (void*)(g.ln_out + ro),
+                                         (OUT8 && g.ln_ascale) ? g.ln_ascale + pm0 + r : nullptr);
+        };
+        // Rows go through in PAIRS out of R = EIGHT register sets: while a pair is normalised, the loads of the six other rows are in
+        // flight.  Why eight: the panel was finished a tile ago and its XCD has written 8 MB since, so the rows come from the
+        // Infinity Cache or HBM, ~3 us a load on a chip busy with GEMM traffic; with four sets (one pair in flight, 48 KB per
+        // CU) the phase ran at 15 GB/s per CU = 52 us per panel — exactly the standalone kernel's HBM-bound rate, i.e. no gain.
+        // Why pairs: a row is one long dependent chain (two wave reductions, a sequential sum of squares); two independent
+        // rows in one basic block let hipcc interleave the chains at two waves per SIMD.
+        // Issue order: L0 .. L7 | wait(L0, L1) S0 S1 L8 L9 | wait(L2, L3) S2 S3 L10 L11 | ...   Younger than a pair at its wait
+        // in the steady state: six load sets and six store sets (12 * LNV <= 60 operations: vmcnt counts to 63); an e4m3 row's
+        // scale is one store more — the wait then covers an operation more than it needs to.
+        // (dim 1280: six sets — eight of 20 registers each do not fit beside gamma and beta; the 32 rows then take six rounds of
+        // six, the last four turns repeat row 31: same bits to the same addresses.)
+        constexpr int R = LNV <= 4 ? 8 : 6;
+        constexpr int TURNS = (32 + R - 1) / R * R;
+        auto turn = [](int i) { return i < 32 ? i : 31; };
+        f32x4 rs[R][LNV > 0 ? LNV : 1];
+#pragma unroll
+        for (int k = 0; k < R; ++k) load_row(rs[k], k);
+        // first group: fewer stores are under way (R - 2, R, R + 2, ... younger sets)
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+          if (q == 0) landed2(rs[0], rs[1], std::integral_constant<int, (R - 2) * LNV>{});
+          else if (q == 1) landed2(rs[2], rs[3], std::integral_constant<int, R * LNV>{});
+          else if (q == 2) landed2(rs[4], rs[5], std::integral_constant<int, (R + 2) * LNV>{});
+          else landed2(rs[R - 2], rs[R - 1], std::integral_constant<int, (R + 4) * LNV>{});      // R = 8 only
+          finish(rs[2 * q], 2 * q); finish(rs[2 * q + 1], 2 * q + 1);
+          load_row(rs[2 * q], turn(R + 2 * q)); load_row(rs[2 * q + 1], turn(R + 2 * q + 1));
+        }
+        using NS = std::integral_constant<int, 2 * (R - 2) * LNV>;
+#pragma unroll 1
+        for (int i = R; i < TURNS; i += R) {
+#pragma unroll
+          for (int q = 0; q < R / 2; ++q) {
+            landed2(rs[2 * q], rs[2 * q + 1], NS{}); finish(rs[2 * q], turn(i + 2 * q)); finish(rs[2 * q + 1], turn(i + 2 * q + 1));
+            load_row(rs[2 * q], turn(i + R + 2 * q)); load_row(rs[2 * q + 1], turn(i + R + 2 * q + 1));     // (past the end: redundant re-loads, the counts stay uniform)
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) landed2(rs[2 * q], rs[2 * q + 1], std::integral_constant<int, 0>{});   // nothing may still be landing in registers the compiler re-uses
+      };
+      if (g.ln_out8) rows(std::true_type{}); else rows(std::false_type{});
+    }
+  };
 #ifdef GEMM_STAGGER
   // experiment (timing builds of tools/gemm_bench only): the workgroups of XCD group x = blockIdx.x & 7 start
   // x * (group_m / 100) * 256 cycles late, so that the eight XCDs' epilogue bursts do not meet in HBM (workgroups of one XCD
@@ -224,8 +350,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   RSTAMP(61);
   int tiles_done = 0;
   bool counted = false;                // previous epilogue took the full-tile path: its last stores may stay in flight
-  bool ln_flushed = false;             // previous tile ended with a LayerNorm phase: every DMA and store before it has landed
-  for (; tile < ntiles; tile = next_of(tile)) {
+  int tile_adv = ntiles;
+  for (; tile < ntiles; tile = tile_adv) {
     ++tiles_done;
     f32x16 acc[C::TM][C::TN];
 #pragma unroll
@@ -241,10 +367,19 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     // (Round 2 experiment, null result: leaving the epilogue's 16 tail stores in flight here — vmcnt(20) instead of vmcnt(4) —
     // changes nothing within the +-3 % run-to-run spread on any shape: wave 0's 5 k cycles at this barrier are the other
     // waves' epilogues, which run at the HBM write rate when all 256 CUs store together, not its own store drain.)
-    if (LNV && ln_flushed)                           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // only h stores in flight
-    else if (counted || (tiles_done == 1 && nk > 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else                                             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    ln_flushed = false;
+    if (counted || (tiles_done == 1 && nk > 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else                                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (LNV > 0) {
+      // what wave 4 left in its staging area at the end of the previous tile: [panel to normalise or -1 | queue position claimed
+      // for the tile after this one].  That area is the A slot of the previous tile's last K-tile: the ring re-fills it with this
+      // tile's A(2), whose first piece goes out behind at least one more barrier.
+      if (tiles_done > 1) {
+        const uint32_t w0 = *(volatile uint32_t*)(smem + lnq_slot), w1 = *(volatile uint32_t*)(smem + lnq_slot + 4);
+        const int ln_panel = __builtin_amdgcn_readfirstlane(w0);
+        lnq_next = pos_tile(__builtin_amdgcn_readfirstlane(w1));
+        if (ln_panel >= 0) ln_phase(ln_panel);
+      }
+    }
     // This tile's bias (one column per lane; fp8: and its dequantisation scale) is taken over HERE: hipcc waits with
     // vmcnt(0) for the (long finished) load in front of its first use, and this is the one point of the tile where nothing
     // worth keeping in flight is in flight (at most the 4 A(1) pieces and the previous epilogue's last 4 stores) — at the
@@ -403,6 +538,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     };
     const int cur_m0 = m0, cur_n0 = n0;                        // this tile's origin (m0 / n0 move on to the next tile below)
     const int next = next_of(tile);
+    tile_adv = next;
     const bool has_next = stream && next < ntiles;
     {
       using T_ = std::true_type; using F_ = std::false_type;
@@ -431,6 +567,23 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       }
     }
     TSTAMP(60);
+    if constexpr (LNV > 0) {
+      // The main loop is over: every wave of the workgroup passed this loop's counted waits long ago, and the first of them retired
+      // the PREVIOUS tile's last stores (they are older than every piece of this loop) — that tile's rows are in the L2.  Wave 4
+      // sends ONE returning atomic: lane 0 claims a queue position (the tile after the next one), lane 1 counts the previous
+      // tile's arrival at its panel.  A compiler-visible atomic: hipcc waits for the result where it is first used — at the
+      // end of this epilogue, microseconds later — and every vector-memory operation younger than it is the epilogue's own, so
+      // the wait it computes is exact and drains nothing of the next tile's stream (those pieces are older).
+      if (wave == 4) {
+        int ls = lane;
+        asm volatile("" : "+v"(ls));
+        if (ls < 2) {
+          const bool arrive = ls == 1 && lnq_prev_panel >= 0;
+          unsigned int* const ap = arrive ? g.ln_sync + 16 + lnq_prev_panel : lnq_queue + xcc;
+          lnq_res = __hip_atomic_fetch_add(ap, (ls == 0 || arrive) ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
 
     // ---------------------------------------------------------------- epilogue
     // acc[a][b][4q + r]: row m = row0 + a*32 + l31 ; column n = col0 + b*32 + 8q + 4*lh + r
@@ -780,75 +933,34 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       }
     }
     if constexpr (LNV > 0) {
-      // ---------------------------------------------------------------- LayerNorm of the finished panel
-      // The panel's last column tile is done: its 256 rows of x are complete, and they are in this XCD's L2 (this very
-      // workgroup wrote them).  Wave w normalises rows w, w + 8, ... exactly as layernorm_bf16_kernel does (one wave per
-      // row, ln_row_finish), R rows per batch with the next batch's loads in flight.  The standalone kernel moves 4.5 KB per
-      // row through HBM (5.6 TB/s: 52 us per 63040 rows); here the reads are L2 hits and only the bf16 rows leave.
-      if (cur_n0 + C::BN >= g.N) {
-        // every wave's x stores must have reached L2 before another wave reads them: vmcnt(0) (a store counts until it is
-        // acknowledged) + workgroup barrier; waves of one workgroup share the CU's vector L1, which is write-through
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        int ll = lane;
-        asm volatile("" : "+v"(ll));                 // opaque: nothing below may be hoisted over the main loop (registers)
-        const int nv = g.N >> 2;
-        f32x4 g4[LNV], b4[LNV];
-#pragma unroll
-        for (int i = 0; i < LNV; ++i) {
-          g4[i] = ((const f32x4*)g.ln_g)[i * 64 + ll]; b4[i] = ((const f32x4*)g.ln_b)[i * 64 + ll];     // N = 256 * LNV: every chunk exists
-        }
-        const int rows_here = g.M - cur_m0 < C::BM ? g.M - cur_m0 : C::BM;
-        const float inv_d = 1.0f / (float)g.N;
-        // wave w: rows w, w + 8, ... (32 of them), two register sets in ping-pong: the loads of row i + 1 are in flight
-        // while row i is normalised.  The loads are inline asm with a counted wait of our own (as for the LDS-DMA): left to
-        // hipcc, every row waited with vmcnt(0) — for its own loads AND the previous row's stores, 1.9 us per row.
-        const uint32_t ll16 = (uint32_t)ll * 16;
-        auto load_row = [&](f32x4 (&dst)[LNV], int i) {
-          int r = wave + 8 * i;
-          r = r < rows_here ? r : rows_here - 1;
-          const char* xr = (const char*)(g.x + (size_t)(cur_m0 + r) * g.ldx);
-#pragma unroll
-          for (int c = 0; c < LNV; ++c)
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst[c]) : "v"(ll16), "s"(xr + c * 1024) : "memory");
-        };
-        // a counted wait that the row registers pass through (no use moves above it): all but the N youngest vector-memory
-        // operations have landed
-        auto landed = [&](f32x4 (&d)[LNV], auto n_c) {
-          constexpr int N = decltype(n_c)::value;
-          if constexpr (LNV == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]) : "n"(N) : "memory");
-          if constexpr (LNV == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "n"(N) : "memory");
-          if constexpr (LNV == 5) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]) : "n"(N) : "memory");
-        };
-        auto rows = [&](auto out8_c) {
-          constexpr bool OUT8 = decltype(out8_c)::value;
-          // rows past the panel's end (last panel only) are clamped to its last row for the load AND the store: the same
-          // bits land on the same address again, and every row costs exactly LNV loads + LNV stores — the counts below
-          auto finish = [&](const f32x4 (&src)[LNV], int i) {
-            int r = wave + 8 * i;
-            r = r < rows_here ? r : rows_here - 1;
-            const size_t ro = (size_t)(cur_m0 + r) * g.ln_ld;
-            ln_row_finish<LNV, true, OUT8>(src, ll, nv, inv_d, g.ln_eps, g4, b4, OUT8 ? (void*)(g.ln_out8 + ro) : (void*)(g.ln_out + ro),
-                                           (OUT8 && g.ln_ascale) ? g.ln_ascale + cur_m0 + r : nullptr);
-          };
-          using N1 = std::integral_constant<int, LNV>;        // younger than the set: the other set's loads
-          using N2 = std::integral_constant<int, 2 * LNV>;    // ... and the previous row's stores (waiting for THOSE cost ~1 us per row)
-          f32x4 ra[LNV], rb[LNV];
-          load_row(ra, 0);
-          load_row(rb, 1);
-          landed(ra, N1{}); finish(ra, 0); load_row(ra, 2);
-#pragma unroll 1
-          for (int i = 1; i < 31; i += 2) {
-            landed(rb, N2{}); finish(rb, i); load_row(rb, i + 2);                           // i + 2 <= 31
-            landed(ra, N2{}); finish(ra, i + 1); load_row(ra, i + 3 < 32 ? i + 3 : 31);     // (the last one is a redundant re-load)
-          }
-          landed(rb, N2{}); finish(rb, 31);
-          landed(ra, std::integral_constant<int, 0>{});     // nothing may still be landing in registers the compiler re-uses
-        };
-        if (g.ln_out8) rows(std::true_type{}); else rows(std::false_type{});
-        ln_flushed = true;
+      // wave 4, done with its own staging area, leaves the two words the next tile's top reads (see there)
+      if (wave == 4) {
+        lnq_claimed = __builtin_amdgcn_readlane(lnq_res, 0);
+        lnq_cnt = __builtin_amdgcn_readlane(lnq_res, 1);
+        const int flagged = (lnq_prev_panel >= 0 && lnq_cnt == g.tiles_n - 1) ? lnq_prev_panel : -1;
+        if (lane == 0) { lds_st_b32(stg, (uint32_t)flagged); lds_st_b32(stg + 4, (uint32_t)lnq_claimed); }
       }
+      lnq_slot = stg_a;
+      lnq_prev_panel = cur_m0 >> 8;
     }
     TSTAMP(40);
+  }
+  if constexpr (LNV > 0) {
+    // The queue is empty.  Two panels may still wait for this workgroup: the one its second-to-last tile belongs to (arrival
+    // counted during the last main loop, result in wave 4's words) and the one of its last tile, whose arrival is sent here,
+    // behind a full drain of every wave's stores.
+    if (tiles_done > 0) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const int first = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)(smem + lnq_slot));
+      if (tid == 256) {
+        const uint32_t before = atomicAdd(g.ln_sync + 16 + lnq_prev_panel, 1u);
+        *(volatile uint32_t*)(smem + lnq_slot + 8) = before == (uint32_t)(g.tiles_n - 1) ? (uint32_t)lnq_prev_panel : 0xffffffffu;
+      }
+      __syncthreads();
+      const int second = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)(smem + lnq_slot + 8));
+      if (first >= 0) ln_phase(first);
+      if (second >= 0) ln_phase(second);
+    }
   }
   STAMP(59);
   RSTAMP(62);

@@ -34,6 +34,14 @@ __global__ void im2col_patch_kernel(const float* __restrict__ px, bf16* __restri
 }
 
 // x[img*N + 0] = cls + pos[0]   (fp32; the concat promotes to fp32 under autocast)
+// What the hardware calls the XCD a workgroup runs on (HW_REG_XCC_ID, bits 3:0) — the fused LayerNorm of gemm256.hip.h keys its
+// work queues on it; the engine looks at one grid's worth of answers at create time.
+__global__ void xcc_probe_kernel(unsigned int* __restrict__ ids) {
+  unsigned int r;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(r));
+  if (threadIdx.x == 0) ids[blockIdx.x] = r & 15u;
+}
+
 __global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
                                int n, RowMap rm, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

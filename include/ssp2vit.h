@@ -83,7 +83,7 @@ int ssp2_set_cu_limit(ssp2_handle h, int n_cu);
  * each one and compares).  Defaults come from the environment variable named beside each, read once in ssp2_create.
  *   SSP2_OPT_ZIGZAG         1  SSP2_ZIGZAG          large launches walk their row panels opposite to the previous launch
  *   SSP2_OPT_ATTN_PERSIST   1  SSP2_ATTN_PERSIST    d_h = 64 / 80 attention on the persistent producer / consumer kernel
- *   SSP2_OPT_LN_FUSION      0  SSP2_LN_FUSION       LayerNorm inside the residual GEMM: 0 off, 1 where a cost model says so, 2 always
+ *   SSP2_OPT_LN_FUSION      0  SSP2_LN_FUSION       LayerNorm inside the residual GEMM (the panel's last-arriving workgroup normalises it): 0 off, 1 / 2 on for every eligible launch
  *   SSP2_OPT_BIG_TILES      1  SSP2_NO_BIG_TILES    launches with >= 4096 rows on the persistent 256 x 256 GEMM
  *   SSP2_OPT_FC1_BIG_TILES  1  SSP2_FC1_SMALL_TILES fc1 of such launches too
  *   SSP2_OPT_GROUP256       0  SSP2_GROUP256        tile order of the 256 x 256 GEMM: 0 = N fastest, 100 * GM + GN = column groups

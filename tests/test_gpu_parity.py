@@ -1241,22 +1241,28 @@ def test_fp8_engine_tracks_the_bf16_engine_within_the_e4m3_tolerance(gpu, cfg):
     ref.close(); f8.close()
 
 
-@pytest.mark.parametrize("cfg,precision", [("vit_base_patch16_224_d3", "bf16"), ("vit_large_patch16_224_d2", "bf16"),
-                                           ("vit_huge_patch14_224_d2", "bf16"), ("vit_base_patch16_224_d3", "fp8")])
-def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_bits(gpu, cfg, precision, monkeypatch):
+@pytest.mark.parametrize("cfg,precision,n_img", [("vit_base_patch16_224_d3", "bf16", 40), ("vit_large_patch16_224_d2", "bf16", 40),
+                                                 ("vit_huge_patch14_224_d2", "bf16", 40), ("vit_base_patch16_224_d3", "fp8", 40),
+                                                 # several tiles per workgroup (the queue's steady state: a panel is normalised two tiles
+                                                 # after it was finished): 126 080 rows x 768 and 82 240 rows x 1280 — the size at which a
+                                                 # missing wait state in front of an inline-asm load showed (csrc/gemm256.hip.h load_row)
+                                                 ("vit_base_patch16_224_d3", "bf16", 640), ("vit_huge_patch14_224_d2", "bf16", 320),
+                                                 ("vit_huge_patch14_224_d2", "fp8", 320)])
+def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_bits(gpu, cfg, precision, n_img, monkeypatch):
     """SSP2_OPT_LN_FUSION (opt-in, csrc/engine.hip ln_fusable; ssp2_set_option): the attention out-projection and fc2 of a launch with >= 4096
-    rows normalise the row panels they finish inside the GEMM kernel (gemm256.hip.h, LNV = dim / 256 = 3, 4, 5; one workgroup
-    per 256-row panel) instead of launching layernorm_bf16_kernel.  Both call ONE row routine (ln_row_finish), so logits,
-    and stage-1 scores must be the same bits — with the attention of a middle block skipped (fc2 then hands
-    LN2 of the next block over, not LN1), with a row count that is not a multiple of 256, and on e4m3 operands (the
-    phase then writes the e4m3 bytes).  '2' forces the fused form for every eligible launch (no cost model)."""
+    rows normalise the row panels they finish inside the GEMM kernel (gemm256.hip.h, LNV = dim / 256 = 3, 4, 5; per-XCD tile
+    queues keyed on the hardware's XCC_ID, the panel's last-arriving workgroup normalises it) instead of launching
+    layernorm_bf16_kernel.  Both call ONE row routine (ln_row_finish), so logits and stage-1 scores must be the same bits —
+    with the attention of a middle block skipped (fc2 then hands LN2 of the next block over, not LN1), with a row count that is
+    not a multiple of 256, and on e4m3 operands (the phase then writes the e4m3 bytes).  '1' and '2' both switch the fused form
+    on for every eligible launch."""
     from ssp2vit.engine import VitEngine
     from ssp2vit.weights import synthetic_weights
     w = synthetic_weights(cfg, classes=10, seed=5, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
     depth = int(w["depth"])
-    eng = VitEngine(w, max_images=40, precision=precision)
+    eng = VitEngine(w, max_images=n_img, precision=precision)
     g = torch.Generator().manual_seed(9)
-    px = torch.randn(40, 3, 224, 224, generator=g).to(gpu)             # 40 x 197 = 7880 / 40 x 257 = 10280 rows: a ragged last panel
+    px = torch.randn(n_img, 3, 224, 224, generator=g).to(gpu)          # 40 x 197 = 7880 / 40 x 257 = 10280 rows: a ragged last panel
     skips = [None] + ([[1]] if depth > 2 else []) + [[0], [depth - 1]]
     def run():
         out = []
@@ -1276,7 +1282,7 @@ def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_
             assert bool(torch.isfinite(a).all())
         else:
             assert a == b
-    eng.set_option("ln_fusion", 1)                                      # the cost model's choice: same bits again
+    eng.set_option("ln_fusion", 1)                                      # the other spelling of "on": same bits again
     for a, b in zip(plain, run()):
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
 

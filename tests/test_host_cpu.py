@@ -543,3 +543,32 @@ def test_cli_launcher_plan_and_flags():
     assert plan["env"]["MASTER_ADDR"] == "127.0.0.1"
     a = cli.build_argparser().parse_args(["--weights", "ck", "--heads", "12", "--gpus", "2", "--target", "0.5"])
     assert (a.weights, a.heads, a.gpus, a.target) == ("ck", 12, 2, 0.5)
+
+
+def test_no_hand_counted_kernel_spills_to_scratch():
+    """The persistent GEMM, the persistent attention kernels and the LDS-staged patch embed count their own vector-memory
+    operations (`s_waitcnt vmcnt(N)` with hand-derived N, csrc/gemm256.hip.h / attn.hip.h / patch.hip.h): a register spill is a
+    scratch load or store the count does not know about, i.e. silently wrong data, not a slowdown.  hipcc reports scratch per
+    kernel (-Rpass-analysis=kernel-resource-usage, a device-only compile: no GPU needed); every instantiation of those
+    kernels must report none."""
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(PKG, "csrc", "engine.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-S", src,
+                          "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900,
+                         cwd=os.path.join(PKG, "csrc"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    name, seen, bad = None, 0, []
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and re.search(r"gemm256_bf16_kernel|attn64_persist_kernel|attn80_persist_kernel|patch_embed_kernel", name):
+            seen += 1
+            if int(m.group(1)) != 0:
+                bad.append((name, int(m.group(1))))
+    assert seen >= 20, f"only {seen} hand-counted kernel instantiations found in the compiler's remarks"
+    assert not bad, f"scratch in hand-counted kernels: {bad}"
