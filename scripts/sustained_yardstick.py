@@ -14,9 +14,18 @@ SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 2.5
 
 
 def _sysfs():
-    """power (uW) and sclk files of the one visible card, whichever of the usual names exist"""
+    """power (uW) and sclk files of the card this process computes on: sysfs shows every card of the host (eight here, other
+    tenants' included), so the card is picked by the PCI address HIP reports for device 0; all of them only if that fails"""
     power, sclk = [], []
-    for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+    cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        mine = [c for c in cards if os.path.realpath(c).endswith(addr)]
+        cards = mine or cards
+    except Exception:
+        pass
+    for card in cards:
         for name in ("power1_average", "power1_input"):
             power += glob.glob(os.path.join(card, "hwmon", "hwmon*", name))
         sclk += glob.glob(os.path.join(card, "hwmon", "hwmon*", "freq1_input"))
