@@ -141,6 +141,28 @@ def pmc_mfma(model="vit_base_patch16_224", precision="bf16"):
         return None
 
 
+def library_yardstick(shape="fc1"):
+    """The committed SUSTAINED library measurement of the dominant family's shape (scripts/sustained_yardstick.py: hipBLASLt,
+    bias-only epilogue, 2.5 s of back-to-back launches, the card's power sampled beside it) — context for `roofline.frac`: on
+    random data these GEMMs run at the card's power cap, and what the vendor's own kernel sustains there is the practical
+    ceiling.  A recorded number of ANOTHER box and run, never part of this run's measurement; None if the file is not there."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sustained_library_yardstick.jsonl")), reverse=True):
+        try:
+            for line in open(path):
+                if not line.startswith('{"shape"'):
+                    continue
+                row = json.loads(line)
+                if row.get("shape") == shape:
+                    lib = row["library(linear+bias)"]
+                    return {"hipblaslt_bias_only_sustained_tflops": lib["sustained_tflops"], "power_w": lib["power_w"], "sclk_mhz": lib["sclk_mhz"],
+                            "shape": [row["M"], row["N"], row["K"]], "source": os.path.basename(path),
+                            "note": "recorded on another box; the library call has no GELU / scoring epilogue"}
+        except Exception:
+            continue
+    return None
+
+
 FAMILIES = (("fc1", ("gemm_fc1",), "fc1 (+bias +erf-GELU; stage 1: + fused activation-L2 partials)"),
             ("resid", ("gemm_fc2", "gemm_proj"), "attention out-projection + fc2 (+bias, fp32 residual read-add-write)"),
             ("qkv", ("gemm_qkv",), "QKV projection (+bias)"),
@@ -590,6 +612,7 @@ def main():
                                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc, "pmc": pmc_mfma(args.model, args.precision),
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
                                 "flops_per_launch_avg": prof.flops / prof.launches,
+                                "library_yardstick": library_yardstick("fc1") if args.precision == "bf16" and args.model == "vit_base_patch16_224" else None,
                                 "shapes": f"[{eng.rows(min(n_calib, calib_chunk), args.batch)} | {eval_chunk * tokens} | {eval_chunk}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk{lm} | CLS tail)"}
         if families is not None:
             dom = max((k for k in families if k != "other"), key=lambda k: families[k]["ms"])
