@@ -407,7 +407,7 @@ def test_persistent_attention_is_bit_identical_to_the_one_item_kernel(gpu, cfg, 
             outs, scs = [], []
             ntok = eng.tokens
             if group:      # slab layout: only the rows of real images are defined
-                mpad = eng.rows(group, group)
+                mpad = eng.rows(2 * group, group) - eng.rows(group, group)     # slab stride (a lone slab is not padded)
                 valid = torch.cat([torch.arange(s0 * mpad, s0 * mpad + min(group, n - s0 * group) * ntok)
                                    for s0 in range((n + group - 1) // group)]).to(gpu)
             else:
