@@ -318,6 +318,14 @@ def test_bench_only_trusts_pmc_summaries_of_the_running_source(tmp_path, monkeyp
     # the summary writers record the hash
     for script in ("pmc_summarize.py", "pmc_mfma.py", "pmc_act_l2.sh"):
         assert "lib_source_hash" in open(os.path.join(root, "scripts", script)).read()
+    # the library yardstick attached to the roofline object is read from a committed record, names its source, and is absent for
+    # shapes the record does not hold
+    (prof / "r98_y_sustained_library_yardstick.jsonl").write_text(
+        '{"sysfs_power": []}\n' + json.dumps({"shape": "fc1", "M": 63040, "N": 3072, "K": 768,
+                                               "library(linear+bias)": {"sustained_tflops": 1160.0, "power_w": 1384.0, "sclk_mhz": 1958.0}}) + "\n")
+    y = bench.library_yardstick("fc1")
+    assert y["hipblaslt_bias_only_sustained_tflops"] == 1160.0 and y["source"] == "r98_y_sustained_library_yardstick.jsonl" and y["shape"] == [63040, 3072, 768]
+    assert bench.library_yardstick("no such shape") is None
 
 
 def test_host_batches_pass_through_on_a_cpu_engine():
