@@ -192,7 +192,8 @@ struct ProfScope {
 // ------------------------------------------------------------------------------------------------ launches
 // Large-M projections go to the 256 x 256 tile kernel (bit-identical results, fewer LDS-DMA issues per MFMA);
 // everything else (small M, fused fc1 epilogue, patch embed, head) stays on the 128 x 128 kernel.
-static const int kBigTileMinRows = 4096;
+static const int kBigTileMinRowsDefault = 4096;   // SSP2_OPT_BIG_TILE_MIN_ROWS
+static inline int big_tile_min_rows(const ssp2_engine* e) { return e->opt[SSP2_OPT_BIG_TILE_MIN_ROWS]; }
 template <int EPI, int SCORE = 0, bool F8 = false>
 static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
   g.tiles_m = (g.M + 255) / 256;
@@ -237,8 +238,14 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
 static int ln_fusable(const ssp2_engine* e, int M, int K, bool f8) {
   const int D = e->d.dim;
   const int on = e->opt[SSP2_OPT_LN_FUSION];
-  if (!on || !e->xcc_ok || M < kBigTileMinRows || D % 256 || D / 256 < 3 || D / 256 > 5 || !e->opt[SSP2_OPT_BIG_TILES]) return 0;
+  if (!on || !e->xcc_ok || M < big_tile_min_rows(e) || D % 256 || D / 256 < 3 || D / 256 > 5 || !e->opt[SSP2_OPT_BIG_TILES]) return 0;
   if (K / (f8 ? 128 : 64) < 2) return 0;
+  // The kernel keeps EIGHT tile queues, one per XCC_ID, and a queue is drained only by workgroups that run on that XCD: all eight
+  // ids must have been seen by the probe (a CPX / DPX partition shows fewer), and the launch must be wide enough that the
+  // dispatcher's round-robin puts workgroups on every XCD — at least 8 per XCD here, which ssp2_set_cu_limit(h, n < 64) or a
+  // launch of fewer than 64 tiles does not give.  Otherwise the standalone LayerNorm runs (same bits).
+  const long tiles = (long)((M + 255) / 256) * (D / 256);
+  if (e->n_xcc_seen != 8 || std::min<long>(tiles, e->n_cu) < 64) return 0;
   return D / 256;
 }
 template <bool F8>
@@ -257,7 +264,7 @@ template <int EPI, int SCORE = 0>
 static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
   if (g.K % GEMM_BK) return fail(SSP2_EINVAL, "GEMM K=%d not a multiple of %d", g.K, GEMM_BK);
   if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID || EPI == EPI_FC1) {
-    if (g.M >= kBigTileMinRows && !(EPI == EPI_FC1 && (g.out2 || !e->opt[SSP2_OPT_FC1_BIG_TILES])) && e->opt[SSP2_OPT_BIG_TILES]) return launch_gemm256<EPI, SCORE>(e, g, klass);
+    if (g.M >= big_tile_min_rows(e) && !(EPI == EPI_FC1 && (g.out2 || !e->opt[SSP2_OPT_FC1_BIG_TILES])) && e->opt[SSP2_OPT_BIG_TILES]) return launch_gemm256<EPI, SCORE>(e, g, klass);
   }
   return launch_gemm_small<EPI, SCORE>(e, g, klass);
 }
@@ -282,7 +289,7 @@ static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const flo
   dim3 grid((rows + 3) / 4), blk(256);
   // one instantiation per row width in 256-element steps: the row lives in MAXV float4 registers per lane, and a
   // wider instantiation than needed drags predicated dead chunks along (ViT-L/16 on <8>: 3.1 TB/s; on <4>: see DESIGN)
-  const int rev = rows >= kBigTileMinRows ? next_dir(e) : 0;
+  const int rev = rows >= big_tile_min_rows(e) ? next_dir(e) : 0;
 #define LN_CASE(V) do { if (D == 256 * V) hipLaunchKernelGGL((layernorm_bf16_kernel<V, true>), grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8, rev, ascale); \
                         else hipLaunchKernelGGL((layernorm_bf16_kernel<V, false>), grid, blk, 0, e->stream, x, in_stride, g, b, y, out_ld, rows, D, e->d.ln_eps, gather, y8, rev, ascale); } while (0)
   if (D <= 256 * 1) LN_CASE(1);
@@ -420,6 +427,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
     e->opt[SSP2_OPT_PATCH_LDS] = env_int("SSP2_PATCH_LDS", 1);
     e->opt[SSP2_OPT_ATTN_STAGGER] = env_int("SSP2_ATTN_STAGGER", 0);
     e->opt[SSP2_OPT_FP8_PROJ] = env_int("SSP2_FP8_PROJ", 1);
+    e->opt[SSP2_OPT_BIG_TILE_MIN_ROWS] = std::max(256, env_int("SSP2_BIG_TILE_MIN_ROWS", kBigTileMinRowsDefault));
   }
   e->d_int.assign(d.d_int, d.d_int + d.depth);
   e->d.d_int = e->d_int.data();
@@ -524,6 +532,7 @@ int ssp2_set_option(ssp2_handle e, int option, int value) {
   if (option < 0 || option >= SSP2_OPT_COUNT) return fail(SSP2_EINVAL, "unknown option %d", option);
   if (option == SSP2_OPT_LN_FUSION && (value < 0 || value > 2)) return fail(SSP2_EINVAL, "SSP2_OPT_LN_FUSION takes 0, 1 or 2");
   if (option == SSP2_OPT_GROUP256 && value < 0) return fail(SSP2_EINVAL, "SSP2_OPT_GROUP256 takes 100 * GM + GN >= 0");
+  if (option == SSP2_OPT_BIG_TILE_MIN_ROWS && value < 256) return fail(SSP2_EINVAL, "SSP2_OPT_BIG_TILE_MIN_ROWS takes >= 256 rows");
   e->opt[option] = value;
   return 0;
 }
@@ -757,7 +766,7 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
   const bool fused = score_site && e->tokens >= GEMM_BM;   // a 128-row tile then spans at most two samples
   // fp8 mode: the three large projections of a launch with >= 4096 rows run on e4m3 operands (LayerNorm and the fc1
   // epilogue write the activation as e4m3 bytes); attention, the out-projection and small launches stay bf16
-  const bool f8 = e->fp8 && M >= kBigTileMinRows;
+  const bool f8 = e->fp8 && M >= big_tile_min_rows(e);
   const bool f8_fc1 = f8 && fused_ok_for_fp8(score_site, e->tokens);
   bool h_ready = false;          // hbuf / hbuf8 already holds the LayerNorm the next projection reads (written by a residual GEMM)
   // x_in: the residual stream ENTERING block l_begin is read from there (LayerNorm input and the first residual add), everything
@@ -1109,11 +1118,12 @@ int ssp2_linear_bf16(void* hip_stream, int epilogue, const uint16_t* a_dev, int 
   ssp2_engine e;
   e.stream = (hipStream_t)hip_stream; e.n_cu = n_cu; e.dev = cur_device();
   e.opt[SSP2_OPT_BIG_TILES] = e.opt[SSP2_OPT_FC1_BIG_TILES] = 1;
+  e.opt[SSP2_OPT_BIG_TILE_MIN_ROWS] = kBigTileMinRowsDefault;
   GemmArgs g{};
   g.A = (const bf16*)a_dev; g.lda = lda; g.W = (const bf16*)w_dev; g.ldw = ldw; g.bias = bias_dev;
   g.M = M; g.N = N; g.K = K; g.tiles_n = ceil_to(N, 256) / GEMM_BN;
   g.out = (bf16*)out_dev; g.ldo = ldo; g.x = x_dev; g.ldx = ldx;
-  const bool big = kernel == 2 || (kernel == 0 && M >= kBigTileMinRows);
+  const bool big = kernel == 2 || (kernel == 0 && M >= kBigTileMinRowsDefault);
   switch (epilogue) {
     case SSP2_EPI_BF16:
       if (!out_dev || ldo < N || (ldo % 8)) return fail(SSP2_EINVAL, "linear: out / ldo");

@@ -154,3 +154,38 @@ def test_vit_b16_headline_geometry_pins_the_oracle():
     assert ref_cpu.select_blocks_torch_argsort(torch.from_numpy(z["att_imp"]), 5) == z["s2_selected_k5"].tolist()
     assert z["att_imp"].shape == (12,) and float(z["top1"]) == 1.0 and sum(len(z[f"labels.{i}"]) for i in range(2)) == 64
     torch.set_num_threads(old_threads)
+
+
+@pytest.mark.parametrize("name,tag,layout", [("vit_large_patch16_224", "vit_l16_2x12", "hf"), ("vit_huge_patch14_224", "vit_h14_2x8", "timm")])
+def test_full_depth_large_geometries_pin_the_oracle(name, tag, layout):
+    """BASELINE.json configs[3] / configs[4] geometries at FULL depth (ViT-L/16: 24 blocks, old-HF anatomy, 2 x 12 images;
+    ViT-H/14: 32 blocks, patch 14, timm anatomy, 2 x 8 images; make_golden.py --l16 / --h14): the oracle's bf16 stage-1 scores
+    equal the REAL reference's bit for bit, its mask step reproduces the reference's masks at the planner's t for 25 / 37.5 / 50 %,
+    its selection rule the reference's argsort selections.  (The depth-importance vector itself — 25 / 33 full passes — was
+    compared when the fixture was made; here the oracle's dense top-1 on the stored teacher labels is re-run.)  ~1 min on 8 cores."""
+    import math
+    import os
+    from ssp2vit.weights import synthetic_weights, VIT_CONFIGS
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(8)                        # the golden was captured with 8 threads (oneDNN splits bf16 GEMMs over them)
+    try:
+        z = dict(np.load(os.path.join(GOLDEN, tag + ".npz")))
+        img, patch, dim, heads, inter, depth = VIT_CONFIGS[name]
+        nb = int(z["n_per_batch"])
+        w = synthetic_weights(name, classes=1000, seed=0, std=0.02, eps=1e-6 if layout == "timm" else 1e-12, spread=4.0)
+        assert math.isclose(sum(float(v.double().sum()) for v in w.values() if isinstance(v, torch.Tensor)), float(z["weights_checksum"]), rel_tol=1e-12)
+        g = torch.Generator().manual_seed(1)
+        batches = [{"pixel_values": torch.randn(nb, 3, img, img, generator=g), "labels": torch.from_numpy(z[f"labels.{i}"])} for i in range(2)]
+        model = build_from_flat(w, layout)
+        imps = ref_cpu.ffn_activation_importance(model, batches)
+        assert len(imps) == depth
+        for i, t in enumerate(imps):
+            assert torch.equal(t.view(torch.int16), bf16_from_bits(z[f"s1_imp_bf16bits.{i}"]).view(torch.int16)), i
+        for K, t in zip(z["plan_K"].tolist(), z["plan_t"].tolist()):
+            mt, _ = ref_cpu.width_prune_selection([x.to(torch.float32) for x in imps], [t] * depth, min_remaining=512)
+            assert np.array_equal(np.packbits(np.asarray(mt, dtype=np.uint8), axis=1), z[f"mask.t{t}"]) and all(sum(m) == t for m in mt)
+            assert ref_cpu.select_blocks_torch_argsort(torch.from_numpy(z["att_imp"]), K) == z[f"s2_selected_k{K}"].tolist()
+        assert z["att_imp"].shape == (depth,)
+        assert ref_cpu.evaluate_top1(model, batches) == float(z["top1"])
+    finally:
+        torch.set_num_threads(old_threads)
