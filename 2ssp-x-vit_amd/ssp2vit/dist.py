@@ -78,6 +78,26 @@ def collective_ms() -> dict:
     return out
 
 
+# Exchange buffers of gather_batch_vectors, allocated ONCE per (device, world size, slots, L, ld) and re-used by every later step:
+# the send block [slots, L, ld] and ONE contiguous receive block [ws, slots, L, ld] (round 3 allocated ws + 1 tensors inside every
+# step, on the timed path of every rank).  The vectors handed back are views of the receive block: valid until the next exchange
+# of the same shape on that device — core.stage1_scores adds them up before it returns.
+_GATHER_BUFFERS = {}
+STATS = {"batches_owned": 0, "exchanges": 0, "buffer_allocations": 0}      # per-process counters (bench.py prints them per rank)
+
+
+def _gather_buffers(dev: torch.device, ws: int, slots: int, L: int, ld: int):
+    key = (str(dev), ws, slots, L, ld)
+    buf = _GATHER_BUFFERS.get(key)
+    if buf is None:
+        if len(_GATHER_BUFFERS) >= 8:
+            _GATHER_BUFFERS.pop(next(iter(_GATHER_BUFFERS)))
+        buf = _GATHER_BUFFERS[key] = (torch.zeros(slots, L, ld, dtype=torch.float32, device=dev),
+                                      torch.empty(ws, slots, L, ld, dtype=torch.float32, device=dev))
+        STATS["buffer_allocations"] += 1
+    return buf
+
+
 def gather_batch_vectors(local: Sequence[Tuple[int, torch.Tensor]], n_batches_total: int, group=None,
                          shape: Optional[Tuple[int, int]] = None) -> List[torch.Tensor]:
     """local = [(global batch index, tensor [L, ld])] owned by this rank (round-robin ownership).
@@ -86,6 +106,7 @@ def gather_batch_vectors(local: Sequence[Tuple[int, torch.Tensor]], n_batches_to
     makes the host wait for the device (the exchange reads a device scalar back)."""
     import torch.distributed as dist
     rank, ws = world(group)
+    STATS["batches_owned"] += len(local)
     if ws == 1 and not (FORCE_COLLECTIVES and _initialised()):
         return [v for _, v in sorted(local, key=lambda p: p[0])]
     if n_batches_total == 0:
@@ -100,13 +121,18 @@ def gather_batch_vectors(local: Sequence[Tuple[int, torch.Tensor]], n_batches_to
         dist.all_reduce(sh, op=dist.ReduceOp.MAX, group=group)         # ranks without a batch learn the shape
         L, ld = int(sh[0]), int(sh[1])
     dev = proto.device if proto is not None else _default_device(group)
-    mine = torch.zeros(slots, L, ld, dtype=torch.float32, device=dev)
+    mine, everyone = _gather_buffers(dev, ws, slots, L, ld)
+    owned = set()
     for idx, v in local:
         assert idx % ws == rank, "batch not owned by this rank"
         mine[idx // ws].copy_(v)
-    everyone = [torch.empty_like(mine) for _ in range(ws)]
+        owned.add(idx // ws)
+    for k in range(slots):                    # slots this rank does not fill this time (ragged ownership): zeros, as a fresh buffer had
+        if k not in owned:
+            mine[k].zero_()
     with _timed("stage1_all_gather", dev):
-        dist.all_gather(everyone, mine, group=group)
+        dist.all_gather_into_tensor(everyone.view(ws * slots, L, ld), mine, group=group)      # concatenation along dim 0: the form every backend takes
+    STATS["exchanges"] += 1
     return [everyone[i % ws][i // ws] for i in range(n_batches_total)]
 
 
@@ -120,7 +146,32 @@ def all_reduce_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
     return counts
 
 
+def device_for_backend(backend: str, cuda_index: Optional[int]) -> torch.device:
+    """Where a rank's exchange tensors live: RCCL ("nccl") moves device memory, so they sit on the rank's current HIP device;
+    every other backend (gloo in the CPU tests) takes host tensors.  Pure: no device is touched here."""
+    if str(backend) == "nccl":
+        if cuda_index is None:
+            raise RuntimeError("backend nccl (RCCL) without a current HIP device")
+        return torch.device("cuda", int(cuda_index))
+    return torch.device("cpu")
+
+
 def _default_device(group=None) -> torch.device:
     import torch.distributed as dist
     backend = dist.get_backend(group)
-    return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    return device_for_backend(backend, torch.cuda.current_device() if (str(backend) == "nccl" and torch.cuda.is_available()) else None)
+
+
+def rank_summary(extra: Optional[dict] = None) -> str:
+    """One line per rank for stderr: who ran where, what it owned, what the exchanges cost — so that a failed or slow
+    multi-rank run can be read off the driver's log tail."""
+    rank, ws = world()
+    dev = "cpu"
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        dev = f"cuda:{i} ({torch.cuda.get_device_name(i)})"
+    parts = [f"[ssp2vit rank {rank}/{ws}] device={dev}", f"backend={__import__('torch.distributed').distributed.get_backend() if _initialised() else 'none'}",
+             f"batches_owned={STATS['batches_owned']}", f"exchanges={STATS['exchanges']}", f"gather_buffer_allocations={STATS['buffer_allocations']}"]
+    for k, v in (extra or {}).items():
+        parts.append(f"{k}={v}")
+    return " ".join(parts)

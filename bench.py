@@ -596,6 +596,12 @@ def main():
     if prof is not None:
         prof.__exit__(None, None, None)
     coll = sdist.collective_ms() if sdist.TIMING else None
+    if world > 1 or "RANK" in os.environ:
+        # one line per rank on stderr: a failed or slow multi-rank run is then readable from the tail of the driver's log
+        print(sdist.rank_summary({"local_ms_per_step": round(elapsed / args.steps * 1e3, 3), "steps": args.steps,
+                                  "calib_batches": n_cal_b, "eval_batches": n_ev_b,
+                                  "collective_ms_per_step": {k: round(v / max(1, args.steps), 3) for k, v in (coll or {}).items()}}),
+              file=sys.stderr, flush=True)
 
     # every kernel family of the step: one more step, untimed, with HIP events around EVERY launch (the timed region above
     # carries events on the fc1 family only, as in rounds 1-2, so `value` stays comparable)

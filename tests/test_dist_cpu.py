@@ -160,6 +160,69 @@ def test_four_rank_gloo_ragged_ownership_equals_single_process(tmp_path, sharded
     assert ref[2][2] == 19
 
 
+def _starved_worker(rank, world, port, out_dir):
+    """4 ranks, 2 batches: ranks 2 and 3 own NOTHING — their exchange tensors come from dist._default_device and the caller-known
+    shape (no shape exchange); three steps in a row re-use ONE pair of exchange buffers."""
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import core, dist as D
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        w, batches = _batches()
+        batches = batches[:2]
+        model = build_from_flat(w, "timm")
+        eng = OracleBackedEngine(model)
+        d_ints = [b.mlp.fc1.out_features for b in model.blocks]
+        assert D._default_device() == torch.device("cpu")
+        outs = [core.stage1_scores(eng, batches, d_ints, "pre_gelu") for _ in range(3)]
+        counts = core.depth_search_counts(eng, batches, eng.depth, batch_limit=None)
+        summary = D.rank_summary({"note": "test"})
+        torch.save((outs, counts, dict(D.STATS), summary), os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ranks_without_a_batch_and_buffer_reuse_over_steps(tmp_path):
+    """world size 4 over TWO batches — two ranks own nothing, so `_default_device` and the `shape=` fast path
+    of gather_batch_vectors run at ws > 1; three consecutive steps allocate the exchange buffers once; every rank reports the
+    one-rank result bit for bit and prints a one-line summary."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import core
+    torch.set_num_threads(1)
+    w, batches = _batches()
+    model = build_from_flat(w, "timm")
+    eng = OracleBackedEngine(model)
+    d_ints = [b.mlp.fc1.out_features for b in model.blocks]
+    ref = core.stage1_scores(eng, batches[:2], d_ints, "pre_gelu")
+    ref_counts = core.depth_search_counts(eng, batches[:2], eng.depth, batch_limit=None)
+    mp.spawn(_starved_worker, args=(4, _free_port(), str(tmp_path)), nprocs=4, join=True)
+    for r in range(4):
+        outs, counts, stats, summary = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        for o in outs:
+            for a, b in zip(o, ref):
+                assert torch.equal(a, b)
+        assert counts == ref_counts
+        assert stats["exchanges"] == 3 and stats["buffer_allocations"] == 1, stats
+        assert stats["batches_owned"] == (3 if r < 2 else 0)
+        assert summary.startswith(f"[ssp2vit rank {r}/4]") and "backend=gloo" in summary and "batches_owned=" in summary
+
+
+def test_exchange_tensors_follow_the_backend():
+    """RCCL ("nccl") exchanges device memory on the rank's current HIP device, gloo host memory (dist.device_for_backend is pure:
+    torch.device objects only, no device is touched — so the nccl branch is checked here, without a GPU)."""
+    from ssp2vit import dist as D
+    assert D.device_for_backend("nccl", 3) == torch.device("cuda", 3)
+    assert D.device_for_backend("gloo", None) == torch.device("cpu") and D.device_for_backend("gloo", 5) == torch.device("cpu")
+    with pytest.raises(RuntimeError):
+        D.device_for_backend("nccl", None)
+    assert "rank 0/1" in D.rank_summary() and "backend=none" in D.rank_summary()
+
+
 def test_gather_is_identity_without_process_group():
     from ssp2vit import dist as D
     v = [(2, torch.ones(1, 2) * 2), (0, torch.zeros(1, 2)), (1, torch.ones(1, 2))]

@@ -814,7 +814,11 @@ def test_full_depth_large_geometries_vs_reference_golden(gpu, name, tag, layout)
     count); the layer-major search reaches (l + 1) x n images per launch.  The dense logits are taken twice — default routing
     (128 x 128 kernel at 12 / 8 images) and with SSP2_OPT_BIG_TILE_MIN_ROWS lowered so the same images meet the large kernel.
     Thresholds (the ViT-B/16 rule, written before the first run on hardware):
-      * bf16_ref chain vs the reference's bf16 scores: <= 2 bf16 ulp (two accumulated batches), >= 90 % identical
+      * bf16_ref chain vs the reference's bf16 scores: >= 90 % identical, and <= 2 bf16 ulp (two accumulated batches of <= 1 ulp
+        each) when the sample count is a power of two, <= 3 ulp otherwise: the chain ends in a bf16 DIVISION by the sample count
+        (reference :200), which is an exact rescaling for 16 / 64 samples, but for ViT-L/16's 24 = 16 x 1.5 a 2-ulp difference of
+        the dividend lands in the lower two thirds of the quotient's binade as 2 x 4/3 = 2.67 ulp and rounds to 3 (the first run
+        on hardware, written against "<= 2", showed exactly that: one element of 98 304 at 3 ulp, in block 1)
       * fp32 chain vs the oracle's fp32-chain scores: rel <= 2e-3 per element
       * masks at the planner's t for 25 / 37.5 / 50 %: identical to the oracle-score masks in EVERY block the product's own report
         calls `guaranteed`; <= one differing bit pair per block on average overall (2 * depth bits)
@@ -853,7 +857,8 @@ def test_full_depth_large_geometries_vs_reference_golden(gpu, name, tag, layout)
         exact = float((ulp == 0).float().mean())
         rel = float(((got_f[l] - ref_f[l]).abs() / ref_f[l].abs().clamp_min(1e-6)).max())
         worst_ulp, worst_exact, worst_rel = max(worst_ulp, int(ulp.max())), min(worst_exact, exact), max(worst_rel, rel)
-        assert int(ulp.max()) <= 2 and exact >= 0.9, (l, int(ulp.max()), exact)
+        ulp_bound = 2 if (n_all & (n_all - 1)) == 0 else 3
+        assert int(ulp.max()) <= ulp_bound and exact >= 0.9, (l, int(ulp.max()), exact)
         assert rel <= 2e-3, (l, rel)
     print(f"[{tag}] stage 1 over {depth} blocks: bf16 chain max {worst_ulp} ulp, >= {100 * worst_exact:.1f} % identical per block | "
           f"fp32 chain rel err max {worst_rel:.2e}")
