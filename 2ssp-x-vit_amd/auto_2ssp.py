@@ -56,6 +56,21 @@ def synthetic_loaders(model, img, batch, n_calib, n_eval_batches, seed, device):
     return test, calib
 
 
+def local_loaders(args, img, device, pg):
+    """--calib-data / --eval-data: (test_loader, cal_loader) over uint8 arrays on disk (ssp2vit.local_data).  Every rank sees the
+    same seeded order and yields only the batches it owns (dist.rank_batch_indices); the hot loops pick `sharded` up from the loader."""
+    from ssp2vit.local_data import Uint8BatchLoader, load_uint8_dataset
+    rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) if pg is not None else (0, 1)
+    mean = tuple(float(v) for v in args.data_mean.split(","))
+    std = tuple(float(v) for v in args.data_std.split(","))
+    ev_x, ev_y = load_uint8_dataset(args.eval_data, args.eval_labels)
+    ca_x, ca_y = load_uint8_dataset(args.calib_data, args.calib_labels)
+    common = dict(out_size=img, mean=mean, std=std, device=device, rank=rank, world=world)
+    test_loader = Uint8BatchLoader(ev_x, ev_y, 64, shuffle=False, random_flip=False, seed=args.seed, **common)               # reference :346
+    cal_loader = Uint8BatchLoader(ca_x, ca_y, 64, shuffle=True, random_flip=True, seed=args.seed, **common)                  # reference :347
+    return test_loader, cal_loader
+
+
 def run_one(args, target, run_id):
     device = "cuda"
     if not torch.cuda.is_available():
@@ -74,11 +89,23 @@ def run_one(args, target, run_id):
         img = VIT_CONFIGS[name][0]
         flat = synthetic_weights(name, classes=args.num_classes, seed=args.seed, std=0.02, spread=4.0)
     model = EngineViT(flat)
-    test_loader, cal_loader = synthetic_loaders(model, img, args.batch_size, args.synthetic_calib, max(args.eval_batches, 1),
-                                                args.seed + 1, device)
+    dataset_desc = "synthetic"
+    if args.calib_data or args.eval_data:
+        # LOCAL image bytes (uint8 HWC arrays on disk) through the GPU input pipeline, with the reference's loader semantics
+        # (load_cifar, reference :268-350: test batch 64 unshuffled / test transform; calibration batch 64 shuffled / train transform
+        # with the random flip) — the network fetch in front of them stays out of scope
+        if not (args.calib_data and args.eval_data):
+            raise SystemExit("--calib-data and --eval-data go together (the search evaluates, the report needs a test set)")
+        test_loader, cal_loader = local_loaders(args, img, device, pg)
+        dataset_desc = f"local uint8: calib {args.calib_data} ({cal_loader.n} images), eval {args.eval_data} ({test_loader.n} images)"
+        if int(test_loader.labels.max()) >= int(flat["classes"]) or int(cal_loader.labels.max()) >= int(flat["classes"]):
+            raise SystemExit(f"labels reach {int(max(test_loader.labels.max(), cal_loader.labels.max()))} but the model has {int(flat['classes'])} classes (--num-classes)")
+    else:
+        test_loader, cal_loader = synthetic_loaders(model, img, args.batch_size, args.synthetic_calib, max(args.eval_batches, 1),
+                                                    args.seed + 1, device)
     if rank0:
-        print(f"[INFO] Using device: {device}; model={name}; synthetic calib={len(cal_loader) * args.batch_size} "
-              f"eval={len(test_loader) * args.batch_size} images; ranks={1 if pg is None else torch.distributed.get_world_size()}")
+        print(f"[INFO] Using device: {device}; model={name}; data={dataset_desc}; calib batches={len(cal_loader)} eval batches={len(test_loader)} "
+              f"of {args.batch_size}; ranks={1 if pg is None else torch.distributed.get_world_size()}")
 
     params_before = vp.count_total_params(model)
     latency_baseline = measure_latency(model, device, img_size=img)
@@ -170,7 +197,7 @@ def run_one(args, target, run_id):
         "config": {"model": name, "target_sparsity": target, "stage": args.stage, "s1_sparsity": args.s1_sparsity,
                    "s2_sparsity": args.s2_sparsity, "freeze_backbone": False, "replace_classifier": False, "use_adapter": False,
                    "adapter_reduction": None, "eval_batches": args.eval_batches, "min_remaining": args.min_remaining,
-                   "cifar_load": False, "dataset": "synthetic", "weights": args.weights,
+                   "cifar_load": False, "dataset": dataset_desc, "weights": args.weights,
                    "gpus": 1 if pg is None else torch.distributed.get_world_size()},
         "metrics": {
             "params_before_stage1": params_before, "params_after_stage1": params_s1, "params_after_stage2": params_s2,
@@ -255,6 +282,14 @@ def build_argparser():
                         "(timm, transformers<5 or transformers>=5 key layout; width-pruned checkpoints load as they are)")
     p.add_argument("--heads", type=int, default=None, help="attention heads, when the checkpoint carries no config.json")
     p.add_argument("--gpus", type=int, default=1, help="N > 1: one process per GPU over RCCL, batches dealt round-robin (starts the ranks itself)")
+    p.add_argument("--calib-data", type=str, default=None,
+                   help="LOCAL calibration images: .npz (images/x/data + labels/y) or .npy (+ --calib-labels or <stem>_labels.npy), uint8 [n,H,W,3]; "
+                        "shuffled by --seed, random flip, batch 64 (the reference's cal_loader), resized / normalised on the GPU")
+    p.add_argument("--eval-data", type=str, default=None, help="LOCAL evaluation images, same formats; batch 64, not shuffled (the reference's test_loader)")
+    p.add_argument("--calib-labels", type=str, default=None)
+    p.add_argument("--eval-labels", type=str, default=None)
+    p.add_argument("--data-mean", type=str, default="0.5,0.5,0.5", help="Normalize mean (the HF ViT processor's image_mean)")
+    p.add_argument("--data-std", type=str, default="0.5,0.5,0.5")
     p.add_argument("--num-classes", type=int, default=1000)
     p.add_argument("--batch-size", type=int, default=64)
     p.add_argument("--synthetic-calib", type=int, default=512)

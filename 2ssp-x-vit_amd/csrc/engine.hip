@@ -132,6 +132,13 @@ struct ssp2_engine {
   int* prune_keep = nullptr;
   size_t prune_t1_cap = 0, prune_t2_cap = 0, prune_tb_cap = 0, prune_keep_cap = 0;
 
+  // keep lists of ssp2_prune_ffn / ssp2_prune_ffn_into cross PCIe out of an ENGINE-OWNED pinned buffer, one slot per layer
+  // (stage_keep): the caller's list may be pinned memory itself, and a copy out of pinned memory is truly asynchronous
+  int32_t* keep_pin = nullptr;
+  size_t keep_pin_slot = 0;
+  std::vector<hipEvent_t> keep_ev;
+  std::vector<char> keep_ev_set;
+
   // profiling: prof_class = one SSP2_K_* class, SSP2_K_COUNT = every class, -1 = off
   int prof_class = -1;
   struct ProfEvent { hipEvent_t a, b; int klass; };
@@ -509,6 +516,8 @@ int ssp2_destroy(ssp2_handle e) {
   for (void* p : e->allocs) hipFree(p);
   hipFree(e->prune_t1); hipFree(e->prune_t2); hipFree(e->prune_tb); hipFree(e->prune_keep);
   if (e->stage_f32) hipFree(e->stage_f32);
+  for (auto ev : e->keep_ev) if (ev) hipEventDestroy(ev);
+  if (e->keep_pin) hipHostFree(e->keep_pin);
   delete e;
   return 0;
 }
@@ -980,6 +989,30 @@ int ssp2_drop_attention(ssp2_handle e, int layer) {
   return 0;
 }
 
+// Host keep list -> device, without relying on the caller's buffer after return.  hipMemcpyAsync stages PAGEABLE sources before it
+// returns, but a PINNED source (hipHostMalloc, torch pin_memory) is read by the DMA engine whenever the stream gets there — the
+// caller may have freed or rewritten the list by then.  The list is therefore copied (host memcpy, <= 20 KB) into the engine's own
+// pinned slot of that layer first; a slot is re-used only by the next prune of the SAME layer, whose event wait is a no-op unless
+// that earlier copy is still queued.
+static int stage_keep(ssp2_engine* e, int layer, const int32_t* keep, int n_keep, int* dev_dst, hipStream_t stream) {
+  const size_t slot = (size_t)std::max(e->ld_int_max, 64);
+  if (!e->keep_pin) {
+    HIPCHK(hipHostMalloc((void**)&e->keep_pin, slot * e->d.depth * sizeof(int32_t)));
+    e->keep_pin_slot = slot;
+    e->keep_ev.assign(e->d.depth, nullptr);
+    e->keep_ev_set.assign(e->d.depth, 0);
+    for (auto& ev : e->keep_ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  if ((size_t)n_keep > e->keep_pin_slot) return fail(SSP2_EINVAL, "keep list of %d entries exceeds the widest block (%zu)", n_keep, e->keep_pin_slot);
+  if (e->keep_ev_set[layer]) HIPCHK(hipEventSynchronize(e->keep_ev[layer]));
+  int32_t* pin = e->keep_pin + (size_t)layer * e->keep_pin_slot;
+  memcpy(pin, keep, (size_t)n_keep * sizeof(int32_t));
+  HIPCHK(hipMemcpyAsync(dev_dst, pin, (size_t)n_keep * 4, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipEventRecord(e->keep_ev[layer], stream));
+  e->keep_ev_set[layer] = 1;
+  return 0;
+}
+
 int ssp2_prune_ffn(ssp2_handle e, int layer, const int32_t* keep, int n_keep) {
   if (!e || !keep || layer < 0 || layer >= e->d.depth) return fail(SSP2_EINVAL, "bad argument");
   Layer& L = e->layers[layer];
@@ -992,8 +1025,8 @@ int ssp2_prune_ffn(ssp2_handle e, int layer, const int32_t* keep, int n_keep) {
   const size_t fc1_elems = (size_t)L.fc1.rows_pad * L.fc1.ld, fc2_elems = (size_t)L.fc2.rows_pad * new_ld;
   // Scratch of the in-place gather lives in the engine: allocated at the first call for the WIDEST block (every later call,
   // on any layer, fits), so a prune is stream-ordered device work — no hipMalloc / hipFree, no stream synchronisation
-  // (round 2: four of each per block and two synchronisations).  The pageable keep list is staged by the runtime before
-  // hipMemcpyAsync returns.
+  // (round 2: four of each per block and two synchronisations).  The keep list crosses PCIe out of the engine's own pinned slot
+  // (stage_keep): the caller's buffer is not read after return, pageable or pinned.
   auto grow = [&](auto** p, size_t& cap, size_t want, size_t worst) -> int {
     if (cap >= want) return 0;
     HIPCHK(hipStreamSynchronize(e->stream));        // (only when a buffer must be replaced: work in flight may still read it)
@@ -1016,7 +1049,7 @@ int ssp2_prune_ffn(ssp2_handle e, int layer, const int32_t* keep, int n_keep) {
   int* const keep_dev = e->prune_keep;
   bf16 *const t1 = e->prune_t1, *const t2 = e->prune_t2;
   float* const tb = e->prune_tb;
-  HIPCHK(hipMemcpyAsync(keep_dev, keep, (size_t)n_keep * 4, hipMemcpyHostToDevice, e->stream));
+  { int rck; if ((rck = stage_keep(e, layer, keep, n_keep, keep_dev, e->stream))) return rck; }
   // fc1: rows gathered, same leading dimension (K = dim); fc2: columns gathered into the new, smaller leading dimension
   hipLaunchKernelGGL(gather_matrix_kernel, dim3(2048), dim3(256), 0, e->stream, L.fc1.w, L.fc1.ld, t1, L.fc1.ld, L.fc1.rows_pad, n_keep, D, keep_dev, (const int*)nullptr);
   hipLaunchKernelGGL(gather_vector_kernel, dim3((L.fc1.rows_pad + 255) / 256), dim3(256), 0, e->stream, L.fc1.b, tb, L.fc1.rows_pad, n_keep, keep_dev);
@@ -1086,8 +1119,7 @@ int ssp2_prune_ffn_into(ssp2_handle dst, ssp2_handle src, int layer, const int32
   if (!(S.fc1.w_set && S.fc1.b_set && S.fc2.w_set)) return fail(SSP2_ESTATE, "layer %d MLP weights not loaded", layer);
   const int D = src->d.dim;
   if (!T.keep_dev) { HIPCHK(hipMalloc((void**)&T.keep_dev, (size_t)T.ld_int * 4)); dst->allocs.push_back(T.keep_dev); }
-  // (pageable source: the runtime stages the bytes before it returns, the caller's list may go away)
-  HIPCHK(hipMemcpyAsync(T.keep_dev, keep, (size_t)n_keep * 4, hipMemcpyHostToDevice, dst->stream));
+  { int rck; if ((rck = stage_keep(dst, layer, keep, n_keep, T.keep_dev, dst->stream))) return rck; }    // the caller's list may go away on return
   hipLaunchKernelGGL(gather_matrix_kernel, dim3(2048), dim3(256), 0, dst->stream, S.fc1.w, S.fc1.ld, T.fc1.w, T.fc1.ld, T.fc1.rows_pad, n_keep, D, (const int*)T.keep_dev, (const int*)nullptr);
   hipLaunchKernelGGL(gather_vector_kernel, dim3((T.fc1.rows_pad + 255) / 256), dim3(256), 0, dst->stream, S.fc1.b, T.fc1.b, T.fc1.rows_pad, n_keep, (const int*)T.keep_dev);
   hipLaunchKernelGGL(gather_matrix_kernel, dim3(2048), dim3(256), 0, dst->stream, S.fc2.w, S.fc2.ld, T.fc2.w, T.fc2.ld, T.fc2.rows_pad, D, n_keep, (const int*)nullptr, (const int*)T.keep_dev);

