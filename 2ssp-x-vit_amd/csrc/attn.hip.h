@@ -18,6 +18,67 @@
 
 #define ATTN_OUT8_SCALE 16.0f        // fp8 mode: attention outputs are written as e4m3(o * 16); the out-projection multiplies by 1 / 16
 
+// ------------------------------------------------------------------------------------------------------------------
+// Softmax numerators of one 32-query tile, in place, shared by every attention kernel of this file (so they stay bit-identical
+// to one another): sacc[kt][i] := exp2((s - rowmax) * scale * log2 e), returns the row sum (lane <-> query; registers and the two
+// lane halves <-> keys: key = 32 kt + (i & 3) + 8 (i >> 2) + 4 lh).  scale > 0, so the row max is taken on the raw scores and the
+// scale folds into the exponent.  Round 4 (the softmax is the kernels' bound: ~4 issue slots per v_exp_f32 — a quarter-rate
+// transcendental — and, before, one v_fma + one v_add + half a v_max3 per score):
+//   * exponent arguments and the row sum on PACKED instructions (v_pk_fma_f32 / v_pk_add_f32: two scores per issue slot); the sum
+//     is therefore formed as two interleaved partial sums — a different association than rounds 1-3 (every kernel changed with it);
+//   * the LAST key tile is mostly padding (197 tokens: 5 valid keys of 32; 257 tokens: 1 of 32): register groups of four whose keys
+//     are past `tokens` on every lane are not exponentiated at all (they are 0, exactly what exp2(-inf) gave) — a wave-uniform
+//     branch per group of the last tile only.  `live_groups` (1..4) is returned so that the P V loop can skip the dead half.
+typedef __attribute__((ext_vector_type(2))) float attn_f32x2;
+template <int NT>
+__device__ __forceinline__ float softmax_tile(f32x16 (&sacc)[NT], const int tokens, const int lh, const float scale, int& live_groups) {
+  const int rem = tokens - 32 * (NT - 1);                  // valid keys of the last tile, 1..32 (wave-uniform)
+  live_groups = __builtin_amdgcn_readfirstlane((rem + 7) >> 3);          // group g = registers 4g..4g+3 = keys 8g + 4 lh + 0..3 of the tile
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NT - 1; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kt][i]);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < live_groups) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = (NT - 1) * 32 + r + 8 * g + 4 * lh;
+        if (key >= tokens) sacc[NT - 1][4 * g + r] = -INFINITY;
+        mx = fmaxf(mx, sacc[NT - 1][4 * g + r]);
+      }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float c2 = scale * 1.44269504088896340736f;
+  const float mc = -mx * c2;
+  attn_f32x2 c2v, mcv, sum2;
+  c2v.x = c2v.y = c2; mcv.x = mcv.y = mc; sum2.x = sum2.y = 0.f;
+  auto pair = [&](f32x16& t, int i) __attribute__((always_inline)) {
+    attn_f32x2 v; v.x = t[i]; v.y = t[i + 1];
+    v = v * c2v + mcv;                                     // one v_pk_fma_f32
+    attn_f32x2 e; e.x = __builtin_amdgcn_exp2f(v.x); e.y = __builtin_amdgcn_exp2f(v.y);
+    t[i] = e.x; t[i + 1] = e.y;
+    sum2 += e;                                             // one v_pk_add_f32
+  };
+#pragma unroll
+  for (int kt = 0; kt < NT - 1; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) pair(sacc[kt], i);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (g < live_groups) { pair(sacc[NT - 1], 4 * g); pair(sacc[NT - 1], 4 * g + 2); }
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sacc[NT - 1][4 * g + r] = 0.f;
+    }
+  }
+  float sum = sum2.x + sum2.y;
+  sum += __shfl_xor(sum, 32);
+  return sum;
+}
+
 // CLS_ONLY (evaluation tail): only query 0 of every image is needed.  q then comes from a compact [n, dim] buffer
 // (q_img_stride = dim, q_ld = 0: the whole 32-query tile reads the CLS row) and only row 0 is stored, into a compact
 // [n, dim] output.  The arithmetic for query 0 is the same instruction sequence as in the full kernel, so the tail
@@ -189,33 +250,9 @@ __global__ __launch_bounds__(256, (DH == 64 ? 2 : 1)) void attn_fwd_kernel(const
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
       }
     }
-    // ---- softmax over keys (registers + the other lane half).  scale > 0, so the row max is taken on the raw
-    // scores and the scale folds into the exponent: p = exp2((s - max) * scale * log2(e)) = one fma + one v_exp.
-    // Only the last key tile can hold keys >= tokens; they are masked to -inf there (exp2 -> 0).
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (kt == NT - 1) {
-          const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-          if (key >= tokens) sacc[kt][i] = -INFINITY;
-        }
-        mx = fmaxf(mx, sacc[kt][i]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float c2 = scale * 1.44269504088896340736f;
-    const float mc = -mx * c2;
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][i], c2, mc));
-        sacc[kt][i] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 32);
+    // ---- softmax over keys (registers + the other lane half): softmax_tile above
+    int live_groups;
+    float sum = softmax_tile<NT>(sacc, tokens, lh, scale, live_groups);
     const float inv = 1.0f / sum;
 
     // ---- O^T = V^T P^T
@@ -231,6 +268,7 @@ __global__ __launch_bounds__(256, (DH == 64 ? 2 : 1)) void attn_fwd_kernel(const
     for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        if (kt == NT - 1 && s2 == 1 && live_groups <= 2) continue;       // keys 16..31 of the last tile are all padding: P = 0 (wave-uniform)
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s2 + j];
@@ -453,30 +491,8 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
       }
     }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (kt == NT - 1) {
-          const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-          if (key >= tokens) sacc[kt][i] = -INFINITY;
-        }
-        mx = fmaxf(mx, sacc[kt][i]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float c2 = scale * 1.44269504088896340736f;
-    const float mc = -mx * c2;
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][i], c2, mc));
-        sacc[kt][i] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 32);
+    int live_groups;
+    float sum = softmax_tile<NT>(sacc, tokens, lh, scale, live_groups);
 #ifdef ATTN_STAMPS
     asm volatile("" : "+v"(sum));
     ASTAMP(n * 4 + 2);                                       // softmax sum known
@@ -492,6 +508,7 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
     for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        if (kt == NT - 1 && s2 == 1 && live_groups <= 2) continue;       // keys 16..31 of the last tile are all padding: P = 0 (wave-uniform)
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s2 + j];
@@ -582,7 +599,7 @@ template <int NT>
 __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                             int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
                                                             int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0) {
-  static_assert(NT >= 8 && NT <= 9, "waves 0..7 take tiles 0..7, wave 0 the ninth");
+  static_assert(NT == 9, "waves 0..7 take tiles 0..7; the ninth tile (one query) is split over the waves by key tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DH = 80, KS = 5, DT = 3, CH = 10, NKEY = NT * 32, RSB = 160, KV = NKEY * RSB;     // 46080 B per operand
   constexpr int NP = NKEY * CH / 64;                                                              // 45 one-KiB pieces per operand
@@ -627,19 +644,77 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
 
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
   const int v_lane_off = (4 * lh + tr_q) * RSB + (16 * tr_g + 4 * tr_p) * 2;
-  const bool two = (NT == 9) && wave == 0;                    // wave 0 also takes the ninth tile
-  // Q fragments: qa = the wave's tile of the CURRENT item, na = of the next item (in flight during this one).  Wave 0 fetches its
-  // ninth tile's fragments into qa once the first tile's scores are done (qa is dead then) and they land during its P V.
-  // 512 threads = 256 registers per lane: 144 score + 48 output accumulators leave room for two fragment sets (three spilled).
+  // The ninth query tile.  ViT-H/14 has 257 tokens: ONE valid query in it.  Rounds 1-3 gave the whole tile to wave 0 (a second full
+  // tile — 45 + 54 MFMAs, 144 exponentials — while seven waves idled at the next barrier: 200 of 1335 ms of the fp8 step).  Round 4
+  // (`split9`, taken when the tile holds exactly one query): the tile is split by KEY tiles over all eight waves, flash-attention
+  // style — wave w takes the query against key tile w (wave 0 also key tile 8, one valid key) right behind its own tile's stores, while
+  // K(i) and V(i) are still in LDS: 5 (10) Q K^T MFMAs, a LOCAL softmax (own maximum m_w, own sum l_w), 6 (9) P V MFMAs; the
+  // partials (m_w, l_w, O_w[80]) go to a 3-KiB LDS scratch, and behind the NEXT item's first barrier one wave combines them:
+  //   M = max m_w,  a_w = exp2((m_w - M) c2),  o = sum a_w O_w / sum a_w l_w
+  // — no extra barrier, no extra register set (the query's fragments come out of LDS: wave 0 sends the row as ONE more DMA piece,
+  // oldest of its item, so the counted wait in front of B2 covers it).  All 32 query columns of those MFMAs hold the same query
+  // (rows past `tokens` are clamped to the last one), so every lane of a half carries the whole result: no extraction step.
+  // Rows 0..255 keep the instruction order of attn_fwd_kernel<80, 9>; row 256 is now summed in another order (local maxima, eight
+  // partial sums): equal within the kernel's tolerance, not bit for bit.
+  // The engine routes a geometry here only when the ninth tile holds exactly one query (257 tokens); anything else runs attn_fwd_kernel.
+  constexpr bool split9 = (NT == 9);
+  char* const xq = smem + 3 * KV + 64;                           // 1 KiB: the extra query's row (160 B used), one DMA piece
+  float* const xpart = (float*)(xq + 1024);                      // [8 waves][96]: O_w[0..79], m_w at 80, l_w at 81
+  // Q fragments: qa = the wave's tile of the CURRENT item, na = of the next item (in flight during this one).
+  // 512 threads = 256 registers per lane: 144 score + 48 output accumulators leave room for the two fragment sets.
   bf16x8 qa[KS], na[KS];
+  const float c2 = scale * 1.44269504088896340736f;
+
+  auto issue_xq = [&](int it) {                                  // wave 0: the extra query's 160-byte row -> xq (lanes >= 10 re-send chunk 9)
+    int head; const size_t r0 = row0_of(it, head);
+    int ls = lane;
+    asm volatile("" : "+v"(ls));
+    const int c = ls < CH ? ls : CH - 1;
+    glds16(qkv + (r0 + (size_t)(tokens - 1)) * ld + head * DH + c * 8, xq);
+  };
+  // the partials of item `it` -> its output row (one wave; lanes 0..39 own two adjacent d each)
+  auto combine_x = [&](int it) {
+    int head; const size_t r0 = row0_of(it, head);
+    int ls = lane;
+    asm volatile("" : "+v"(ls));
+    float m[8], M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { m[w] = xpart[w * 96 + 80]; M = fmaxf(M, m[w]); }
+    float L = 0.f, o0 = 0.f, o1 = 0.f;
+    const int d = 2 * (ls < 40 ? ls : 39);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const float a = __builtin_amdgcn_exp2f((m[w] - M) * c2);
+      L = fmaf(a, xpart[w * 96 + 81], L);
+      o0 = fmaf(a, xpart[w * 96 + d], o0);
+      o1 = fmaf(a, xpart[w * 96 + d + 1], o1);
+    }
+    const float inv = 1.0f / L;
+    if (ls < 40) {
+      const size_t row = r0 + (size_t)(tokens - 1);
+      if (out8) {
+        const uint32_t pk = pack_e4m3x4_from(o0 * inv * ATTN_OUT8_SCALE, o1 * inv * ATTN_OUT8_SCALE, 0.f, 0.f);
+        *(uint16_t*)(out8 + row * (size_t)ldo8 + head * DH + d) = (uint16_t)pk;
+      } else {
+        bf16x2 o2; o2[0] = (bf16)(o0 * inv); o2[1] = (bf16)(o1 * inv);
+        *(bf16x2*)(out + row * ldo + head * DH + d) = o2;
+      }
+    }
+  };
 
   int it = blockIdx.x;
   if (it < n_items) {
+    if (split9 && wave == 0) issue_xq(it);
     issue(it, 1, K0);
     load_q_asm(it, wave, na);
   }
+  int prev_it = -1;
   for (int b = 0; it < n_items; it += G, b ^= 1) {            // workgroup-uniform trip count
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                              // B1(i)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                   // B1(i)  (lgkmcnt: the extra query's partials are LDS stores)
+    if (split9 && prev_it >= 0) {
+      if (wave == 7) combine_x(prev_it);                       // the previous item's extra query (its partials predate B1)
+      if (wave == 0) issue_xq(it);                             // this item's: every wave has read the previous row (before B1); OLDEST DMA of the item
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) qa[s] = na[s];
     const bool more = it + G < n_items;
@@ -653,6 +728,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
     // S^T = K Q^T and the softmax for the wave's tile(s); the score accumulators stay in registers across B2
     f32x16 sacc[NT];
     float inv;
+    int live_groups = 4;
     auto scores = [&](const bf16x8 (&qf)[KS]) {
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
@@ -665,30 +741,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
           sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
         }
       }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (kt == NT - 1) {
-            const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            if (key >= tokens) sacc[kt][i] = -INFINITY;
-          }
-          mx = fmaxf(mx, sacc[kt][i]);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float c2 = scale * 1.44269504088896340736f;
-      const float mc = -mx * c2;
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][i], c2, mc));
-          sacc[kt][i] = e;
-          sum += e;
-        }
-      sum += __shfl_xor(sum, 32);
+      const float sum = softmax_tile<NT>(sacc, tokens, lh, scale, live_groups);
       inv = 1.0f / sum;
     };
     auto pv_store = [&](int qt) {
@@ -701,6 +754,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
       for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+          if (kt == NT - 1 && s2 == 1 && live_groups <= 2) continue;     // keys 16..31 of the last tile are all padding: P = 0 (wave-uniform)
           bf16x8 pf;
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s2 + j];
@@ -739,24 +793,99 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
           }
       }
     };
+    // The extra query against this wave's key tile(s): local softmax, partial O -> xpart (see `split9` above)
+    auto extra_partial = [&]() {
+      bf16x8 qx[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) qx[s] = *(const bf16x8*)(xq + 32 * s + 16 * lh);       // every lane: the same query (broadcast reads)
+      f32x16 sx[2];
+      const bool second = (wave == 0);                           // wave 0: key tiles 0 and 8
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sx[j][i] = 0.f;
+        if (j == 1 && !second) continue;
+        const int kt = j ? NT - 1 : wave;
+        const char* kp = Ks + (kt * 32 + l31) * RSB + 16 * lh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const bf16x8 kf = *(const bf16x8*)(kp + 32 * s);
+          sx[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qx[s], sx[j], 0, 0, 0);
+        }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sx[0][i]);
+      // key tile 8: only key 256 = register 0 of the lower lane half is a token (tokens = 257)
+      if (second && lh == 0) mx = fmaxf(mx, sx[1][0]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mc = -mx * c2;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float e = __builtin_amdgcn_exp2f(fmaf(sx[0][i], c2, mc)); sx[0][i] = e; sum += e; }
+      {
+        const float e = (second && lh == 0) ? __builtin_amdgcn_exp2f(fmaf(sx[1][0], c2, mc)) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sx[1][i] = 0.f;
+        sx[1][0] = e; sum += e;
+      }
+      sum += __shfl_xor(sum, 32);
+      f32x16 ox[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ox[dt][i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !second) continue;
+        const int kt = j ? NT - 1 : wave;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          if (j == 1 && s2 == 1) continue;                       // keys 272.. : padding
+          bf16x8 pf;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pf[k] = (bf16)sx[j][8 * s2 + k];
+          const char* vp = Vb + (kt * 32 + 16 * s2) * RSB + v_lane_off;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp + dt * 64));
+            const bf16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vp + dt * 64 + 8 * RSB));
+            bf16x8 vf;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { vf[k] = v1[k]; vf[4 + k] = v2[k]; }
+            ox[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ox[dt], 0, 0, 0);
+          }
+        }
+      }
+      // query column 0 (lanes 0 and 32) writes: d = dt * 32 + 8 g4 + 4 lh + 0..3
+      if (l31 == 0) {
+        float* const dst = xpart + wave * 96;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = dt * 32 + 8 * g4 + 4 * lh;
+            if (d0 < DH) {
+              f32x4 v; v.x = ox[dt][4 * g4]; v.y = ox[dt][4 * g4 + 1]; v.z = ox[dt][4 * g4 + 2]; v.w = ox[dt][4 * g4 + 3];
+              *(f32x4*)(dst + d0) = v;
+            }
+          }
+        if (lh == 0) { dst[80] = mx; dst[81] = sum; }
+      }
+    };
 
     scores(qa);
-    // B2(i): V(i) has landed on every wave (its 6 pieces are older than the 6 of K(i+1), when there is a next item)
+    // B2(i): V(i) has landed on every wave (its 6 pieces are older than the 6 of K(i+1), when there is a next item; wave 0's
+    // extra-query piece is older still)
     if (more) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     else      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (two) load_q_asm(it, 8, qa);                            // behind B2, so that the counted wait above keeps its meaning
     pv_store(wave);
-    if (two) {                                                 // the ninth tile: K[i & 1] and V are both still valid
-      {   // its fragments have landed (and, older, K(i+1)): a wait the uses of qa cannot move above
-        f32x4 t0 = __builtin_bit_cast(f32x4, qa[0]), t1 = __builtin_bit_cast(f32x4, qa[1]), t2 = __builtin_bit_cast(f32x4, qa[2]),
-              t3 = __builtin_bit_cast(f32x4, qa[3]), t4 = __builtin_bit_cast(f32x4, qa[4]);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4) :: "memory");
-        qa[0] = __builtin_bit_cast(bf16x8, t0); qa[1] = __builtin_bit_cast(bf16x8, t1); qa[2] = __builtin_bit_cast(bf16x8, t2);
-        qa[3] = __builtin_bit_cast(bf16x8, t3); qa[4] = __builtin_bit_cast(bf16x8, t4);
-      }
-      scores(qa);
-      pv_store(8);
-    }
+    if (split9) extra_partial();
+    prev_it = it;
+  }
+  if (split9 && prev_it >= 0) {                                // the last item's extra query
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wave == 7) combine_x(prev_it);
   }
 }
 

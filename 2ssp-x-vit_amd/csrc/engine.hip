@@ -213,6 +213,7 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
     HIPCHK(hipFuncSetAttribute((const void*)gemm256_bf16_kernel<EPI, SCORE, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, G256::LDS));
     attr_done[e->dev] = true;
   }
+  g.nt_out = e->opt[SSP2_OPT_NT_STORES];
   if (!(EPI == EPI_RESID && SCORE > 0)) g.reverse = next_dir(e);
   else { g.ln_sync = e->ln_sync; g.ln_set = e->ln_set; e->ln_set ^= 1; }      // LayerNorm behind the epilogue: per-XCD tile queues
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
@@ -346,10 +347,11 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullp
       return 0;
     }
   }
-  if constexpr (DH == 80 && !CLS && NT >= 8 && NT <= 9) {
-    // persistent form for d_h = 80 (ViT-H/14): two K buffers + one V buffer, every wave consumer and DMA issuer (attn.hip.h)
-    if (e->opt[SSP2_OPT_ATTN_PERSIST]) {
-      constexpr int psmem = 3 * NT * 32 * 160 + 64;
+  if constexpr (DH == 80 && !CLS && NT == 9) {
+    // persistent form for d_h = 80 (ViT-H/14): two K buffers + one V buffer, every wave consumer and DMA issuer (attn.hip.h);
+    // its ninth query tile must hold exactly one query (257 tokens), which it splits over the waves by key tile
+    if (e->opt[SSP2_OPT_ATTN_PERSIST] && e->tokens == 32 * (NT - 1) + 1) {
+      constexpr int psmem = 3 * NT * 32 * 160 + 64 + 1024 + 8 * 96 * 4;      // K ring + V + slack + the split ninth tile's query row and partials (attn.hip.h)
       static bool pattr_done[kMaxDevices] = {};
       if (!pattr_done[e->dev]) {
         HIPCHK(hipFuncSetAttribute((const void*)attn80_persist_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, psmem));
@@ -378,7 +380,7 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullp
 // which geometries have a persistent kernel (the ones that can write the e4m3 output)
 static bool attn_persistent(const ssp2_engine* e) {
   const int nt = (e->tokens + 31) / 32;
-  return e->opt[SSP2_OPT_ATTN_PERSIST] && ((e->dh == 64 && nt >= 4 && nt <= 7) || (e->dh == 80 && nt >= 8 && nt <= 9));
+  return e->opt[SSP2_OPT_ATTN_PERSIST] && ((e->dh == 64 && nt >= 4 && nt <= 7) || (e->dh == 80 && nt == 9 && e->tokens == 257));
 }
 static int launch_attn(ssp2_engine* e, int n, RowMap rm, bool cls_only = false, uint8_t* out8 = nullptr) {
   const int nt = (e->tokens + 31) / 32;
@@ -435,6 +437,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
     e->opt[SSP2_OPT_ATTN_STAGGER] = env_int("SSP2_ATTN_STAGGER", 0);
     e->opt[SSP2_OPT_FP8_PROJ] = env_int("SSP2_FP8_PROJ", 1);
     e->opt[SSP2_OPT_BIG_TILE_MIN_ROWS] = std::max(256, env_int("SSP2_BIG_TILE_MIN_ROWS", kBigTileMinRowsDefault));
+    e->opt[SSP2_OPT_NT_STORES] = env_int("SSP2_NT_STORES", 1);
   }
   e->d_int.assign(d.d_int, d.d_int + d.depth);
   e->d.d_int = e->d_int.data();

@@ -53,6 +53,7 @@ struct GemmArgs {
   // EPI_PATCH
   const float* pos; int patches;
   int group_m;                // row tiles per L2 super-tile (0 = plain N-fastest order)
+  int nt_out;                 // gemm256 kernel: bf16 / e4m3 activation outputs leave as NON-TEMPORAL stores (SSP2_OPT_NT_STORES)
   int reverse;                // gemm256: walk the tiles from the last to the first (see engine.hip, zigzag)
   // fp8 (e4m3) operands, gemm256 kernel with F8 = true only: A and W point at BYTES (lda / ldw / K count fp8 elements,
   // K a multiple of 128), acc is multiplied by wscale[n] (the weight row's dequantisation scale) before the bias;

@@ -728,7 +728,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
               const int r = it * 16 + (le >> 2), c = (le & 3) * 16;
               const i32x4 v = *(const i32x4*)(stg + r * 64 + c);
               const int m = row0 + h * 64 + r;
-              if (m < g.M) *(i32x4*)((char*)g.out + (size_t)m * g.ldo + col0 + c) = v;
+              if (m < g.M) { if (g.nt_out) __builtin_nontemporal_store(v, (i32x4*)((char*)g.out + (size_t)m * g.ldo + col0 + c)); else *(i32x4*)((char*)g.out + (size_t)m * g.ldo + col0 + c) = v; }
             }
           } else {
 #pragma unroll
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             const int r = it * 8 + (le >> 3), c = (le & 7) * 8;
             const bf16x8 v = *(const bf16x8*)(stg + r * 128 + c * 2);
             const int m = row0 + h * 64 + r;
-            if (m < g.M) *(bf16x8*)(g.out + (size_t)m * g.ldo + col0 + c) = v;
+            if (m < g.M) { if (g.nt_out) __builtin_nontemporal_store(v, (bf16x8*)(g.out + (size_t)m * g.ldo + col0 + c)); else *(bf16x8*)(g.out + (size_t)m * g.ldo + col0 + c) = v; }
           }
           }
         }
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
           for (int it = 0; it < 4; ++it) {
             const int r = it * 16 + (le >> 2), c = le & 3;
             const int m = row0 + h * 64 + r;
-            if (m < g.M) *(i32x4*)((char*)g.out + (size_t)m * g.ldo + col0 + c * 16) = v[it];
+            if (m < g.M) { if (g.nt_out) __builtin_nontemporal_store(v[it], (i32x4*)((char*)g.out + (size_t)m * g.ldo + col0 + c * 16)); else *(i32x4*)((char*)g.out + (size_t)m * g.ldo + col0 + c * 16) = v[it]; }
           }
         }
       }
@@ -831,11 +831,19 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
           for (int it = 0; it < 8; ++it) v[it] = *(const bf16x8*)(rd_lane + it * 1024);
           WAITL0();
           if (h == 0) TSTAMP(47);
+          if (g.nt_out) {           // (wave-uniform) non-temporal: the tile is read next by ANOTHER kernel, it need not stay in this XCD's L2
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+              bf16* dst = out_lane + (size_t)(h * 64 + it * 8) * g.ldo;
+              if (full || row0 + h * 64 + it * 8 + (le >> 3) < g.M) __builtin_nontemporal_store(v[it], (bf16x8*)dst);
+            }
+          } else {
 #pragma unroll
           for (int it = 0; it < 8; ++it) {
             bf16* dst = out_lane + (size_t)(h * 64 + it * 8) * g.ldo;
             if (full) ST_OUT((bf16x8*)dst, v[it]);
             else if (row0 + h * 64 + it * 8 + (le >> 3) < g.M) ST_OUT((bf16x8*)dst, v[it]);
+          }
           }
           if (h == 0) TSTAMP(48);
         }

@@ -522,12 +522,14 @@ def impacts_from_counts(base: int, cand: Sequence[int], total: int) -> List[floa
     return [max(0.0, baseline - float(c / max(1, total))) for c in cand]
 
 
-def select_for_targets(imps: Sequence[torch.Tensor], impact: torch.Tensor, plans: Sequence, min_remaining: int = 256) -> List[dict]:
+def select_for_targets(imps: Sequence[torch.Tensor], impact: torch.Tensor, plans: Sequence, min_remaining: int = 256,
+                       site: Optional[str] = None) -> List[dict]:
     """The host half of a prune for one or several targets from ONE stage-1 pass and ONE search (BASELINE configs[2]:
     25 / 37.5 / 50 % — the sweep convention of main.py:152-157): per plan the a7 mask step on the final score vectors
     (reference src/vit_pruning.py:273-295: keep = sort(argsort(imp, descending)[:d_int - t]), 1 = prune; t clamped per block so
     that at least `min_remaining` neurons stay, :279-281 — the default is prune_vit_mlp_width's), the a9 block
-    selection `torch.argsort(att_imp)[:K]` (auto_2ssp.py:857) and the cut-margin table of those masks.
+    selection `torch.argsort(att_imp)[:K]` (auto_2ssp.py:857) and the cut-margin table of those masks (`site`: the hook site
+    the scores were taken at — the post-GELU site gets the wider tie band, ssp2vit/mask_parity.py).
     Returns [{"target", "masks": [int16 [d_int]] * L, "blocks": sorted [int], "mask_parity": {...}}]."""
     impact = torch.as_tensor(impact, dtype=torch.float32)
     out = []
@@ -543,5 +545,5 @@ def select_for_targets(imps: Sequence[torch.Tensor], impact: torch.Tensor, plans
             masks.append(m)
         blocks = sorted(int(i) for i in torch.argsort(impact)[: int(p.blocks_to_prune)])
         out.append({"target": float(p.target_sparsity), "masks": masks, "blocks": blocks,
-                    "mask_parity": mask_parity_report(imps, [t] * len(imps), min_remaining=int(min_remaining))})
+                    "mask_parity": mask_parity_report(imps, [t] * len(imps), min_remaining=int(min_remaining), site=site)})
     return out

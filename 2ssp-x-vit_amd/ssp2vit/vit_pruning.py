@@ -263,8 +263,13 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
     if collect_masks:
         # the reference's three keys (:313-318) + this build's cut-margin table for the very scores the masks were cut from
         return {"model": vit_model, "ffn_pruned_indices": all_idx, "ffn_prune_masks": all_masks,
-                "mask_parity": mask_parity_report(used_scores, used_drop, min_remaining=0)}
+                "mask_parity": mask_parity_report(used_scores, used_drop, min_remaining=0, site=_score_site_of(vit_model))}
     return vit_model
+
+
+def _score_site_of(vit_model) -> str:
+    """Hook site of the stage-1 scores for this module's anatomy (reference :130 HF post-GELU, :135 timm pre-GELU)."""
+    return getattr(vit_model, "ssp2_score_site", None) or _weights.score_site_for("timm" if _blocks(vit_model)[1] == "timm" else "hf")
 
 
 # ----------------------------------------------------------------------------- a4 top-1

@@ -62,7 +62,9 @@ def test_width_prune_mask_step_matches_reference_golden(layout):
     assert np.array_equal(np.asarray(res["ffn_pruned_indices"]), z["pruned_idx.t40"])
     assert res["model"] is model
     mp = res["mask_parity"]                              # this build's fourth key: cut margins of the masks just made
-    assert mp["blocks_total"] == 4 and [b["pruned"] for b in mp["blocks"]] == [40] * 4 and mp["eps"] == vp.MASK_PARITY_EPS
+    from ssp2vit.mask_parity import MASK_PARITY_EPS_POST_GELU       # the old-HF anatomy hooks post-GELU: the wider tie band
+    assert mp["blocks_total"] == 4 and [b["pruned"] for b in mp["blocks"]] == [40] * 4
+    assert mp["eps"] == (vp.MASK_PARITY_EPS if layout == "timm" else MASK_PARITY_EPS_POST_GELU) and mp["score_site"] == ("pre_gelu" if layout == "timm" else "post_gelu")
     # weight surgery equals the reference's: the pruned model's top-1 (oracle forward) equals the stored value
     assert ref_cpu.evaluate_top1(model, batches) == float(z["top1_after.t40"])
     pairs = vp._gather_mlp_pairs(model)
