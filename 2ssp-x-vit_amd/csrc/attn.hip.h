@@ -26,14 +26,24 @@
 // transcendental — and, before, one v_fma + one v_add + half a v_max3 per score):
 //   * exponent arguments and the row sum on PACKED instructions (v_pk_fma_f32 / v_pk_add_f32: two scores per issue slot); the sum
 //     is therefore formed as two interleaved partial sums — a different association than rounds 1-3 (every kernel changed with it);
-//   * the LAST key tile is mostly padding (197 tokens: 5 valid keys of 32; 257 tokens: 1 of 32): register groups of four whose keys
-//     are past `tokens` on every lane are not exponentiated at all (they are 0, exactly what exp2(-inf) gave) — a wave-uniform
-//     branch per group of the last tile only.  `live_groups` (1..4) is returned so that the P V loop can skip the dead half.
+//   * (ATTN_SKIP_DEAD, built, measured, OFF) the LAST key tile is mostly padding (197 tokens: 5 valid keys of 32; 257 tokens: 1 of
+//     32): register groups of four whose keys are past `tokens` on every lane need no exponential (they are 0, exactly what
+//     exp2(-inf) gives) — a wave-uniform branch per group of the last tile, and `live_groups` (1..4) lets the P V loop skip the dead
+//     half.  Same bits, and 3-5 % SLOWER on the 197-token kernel (tools/attn_bench, 3520 items: 1043-1060 us against 1000-1022 with
+//     the padding computed; profiles/r04_g_attn_ab.txt): the branches cut the one basic block in which hipcc interleaves the
+//     exponentials with the MFMAs of the next phase.  Packing alone: 1000 us against 1008-1022 (+1-2 %).
+// A/B switches (timing builds of tools/attn_bench only; the product builds with both on)
+#ifndef ATTN_SOFTMAX_PACKED
+#define ATTN_SOFTMAX_PACKED 1
+#endif
+#ifndef ATTN_SKIP_DEAD
+#define ATTN_SKIP_DEAD 0
+#endif
 typedef __attribute__((ext_vector_type(2))) float attn_f32x2;
 template <int NT>
 __device__ __forceinline__ float softmax_tile(f32x16 (&sacc)[NT], const int tokens, const int lh, const float scale, int& live_groups) {
   const int rem = tokens - 32 * (NT - 1);                  // valid keys of the last tile, 1..32 (wave-uniform)
-  live_groups = __builtin_amdgcn_readfirstlane((rem + 7) >> 3);          // group g = registers 4g..4g+3 = keys 8g + 4 lh + 0..3 of the tile
+  live_groups = ATTN_SKIP_DEAD ? __builtin_amdgcn_readfirstlane((rem + 7) >> 3) : 4;          // group g = registers 4g..4g+3 = keys 8g + 4 lh + 0..3 of the tile
   float mx = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < NT - 1; ++kt)
@@ -56,11 +66,17 @@ __device__ __forceinline__ float softmax_tile(f32x16 (&sacc)[NT], const int toke
   attn_f32x2 c2v, mcv, sum2;
   c2v.x = c2v.y = c2; mcv.x = mcv.y = mc; sum2.x = sum2.y = 0.f;
   auto pair = [&](f32x16& t, int i) __attribute__((always_inline)) {
+#if ATTN_SOFTMAX_PACKED
     attn_f32x2 v; v.x = t[i]; v.y = t[i + 1];
     v = v * c2v + mcv;                                     // one v_pk_fma_f32
     attn_f32x2 e; e.x = __builtin_amdgcn_exp2f(v.x); e.y = __builtin_amdgcn_exp2f(v.y);
     t[i] = e.x; t[i + 1] = e.y;
     sum2 += e;                                             // one v_pk_add_f32
+#else
+    const float e0 = __builtin_amdgcn_exp2f(fmaf(t[i], c2, mc)), e1 = __builtin_amdgcn_exp2f(fmaf(t[i + 1], c2, mc));
+    t[i] = e0; t[i + 1] = e1;
+    sum2.x += e0; sum2.x += e1;
+#endif
   };
 #pragma unroll
   for (int kt = 0; kt < NT - 1; ++kt)

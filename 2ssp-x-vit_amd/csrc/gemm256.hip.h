@@ -895,12 +895,18 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         const int rows_left = g.M - row0 - dr;                       // row a*32 + 8j + dr is valid iff a*32 + 8j < rows_left
         auto voff = [&](int a, int j) -> int { return (a * 32 + 8 * j < rows_left) ? lane_off : 0x7fffffff; };
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        // cache policy of the x tile (aux operand of the raw-buffer instructions: bit 1 = nt).  GEMM_XNT: 1 = loads non-temporal (the
+        // tile is read once here), 2 = stores, 3 = both — a timing switch of tools/gemm_bench, see DESIGN.md for what it measured
+#ifndef GEMM_XNT
+#define GEMM_XNT 0
+#endif
+        constexpr int XLD_AUX = (GEMM_XNT & 1) ? 2 : 0, XST_AUX = (GEMM_XNT & 2) ? 2 : 0;
         f32x4 xin[NXB][4];
 #pragma unroll
         for (int p = 0; p < NXB; ++p)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            xin[p][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_in, voff(p >> 1, j), xoff(p >> 1, p & 1, j), 0));
+            xin[p][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_in, voff(p >> 1, j), xoff(p >> 1, p & 1, j), XLD_AUX));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -924,7 +930,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), xr, voff(a, j), xoff(a, b, j), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), xr, voff(a, j), xoff(a, b, j), XST_AUX);
           // ... and two wait states before anything may rewrite the stores' data registers (16-byte store data with an
           // SGPR offset: hipcc / ROCm 7.2 does not pad this case on gfx950, see above) — an instruction-order-independent
           // guard, so that a scheduling change in a later compiler cannot bring the corruption back
@@ -934,7 +940,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0); // hoist these loads to the top and spill their destinations)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              xin[p % NXB][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_in, voff((p + NXB) >> 1, j), xoff((p + NXB) >> 1, (p + NXB) & 1, j), 0));
+              xin[p % NXB][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_in, voff((p + NXB) >> 1, j), xoff((p + NXB) >> 1, (p + NXB) & 1, j), XLD_AUX));
             __builtin_amdgcn_sched_barrier(0);
           }
         }

@@ -548,10 +548,11 @@ def test_cli_on_local_uint8_data_through_the_gpu_input_pipeline(gpu, tmp_path):
     for b in loader:                                                   # epoch 0
         out = b["preprocess"](b["pixel_values"], b["hflip"])
         _, u8 = b["preprocess"](b["pixel_values"], None, return_u8=True)       # the resized bytes, unflipped (Pillow-pinned elsewhere)
-        ref = u8.permute(0, 3, 1, 2).contiguous().to(torch.float32).div(255).sub(0.5).div(0.5)
-        flip = b["hflip"].bool().to(out.device)
+        # ToTensor / Normalize stated on the CPU, as torchvision runs them (a device tensor's .div(255) multiplies by the reciprocal: 1 ulp off)
+        ref = u8.cpu().permute(0, 3, 1, 2).contiguous().to(torch.float32).div(255).sub(0.5).div(0.5)
+        flip = b["hflip"].bool()
         ref[flip] = ref[flip].flip(-1)
-        assert torch.equal(out, ref)
+        assert torch.equal(out.cpu(), ref)
         fp32_batches.append({"pixel_values": out.clone()})
     assert [int(b["pixel_values"].shape[0]) for b in fp32_batches] == [64, 16]
     w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=0, std=0.02, spread=4.0)
@@ -907,9 +908,14 @@ def test_full_depth_large_geometries_vs_reference_golden(gpu, name, tag, layout)
       * masks at the planner's t for 25 / 37.5 / 50 %: identical to the oracle-score masks in EVERY block the product's own report
         calls `guaranteed`; <= one differing bit pair per block on average overall (2 * depth bits)
       * dense logits of batch 0 vs the oracle's: |err| <= 2^-6 * max|logit| (both routings), the two routings bit-identical
-      * dense top-1 on the teacher labels within 1 image; every candidate's impact within 2 images of the reference's; the product's
-        selection == torch.argsort(impact)[:K], and every selected block's REFERENCE impact <= the reference's K-th smallest
-        + 4 images (twice the per-impact tolerance: a theorem given the line above)."""
+      * stage 2 on the reference's teacher labels.  The weights are random-init: the logits are nearly flat (max |logit| ~ 2.4) and an
+        image whose top-2 margin is below twice the logit error may legitimately land on either class.  The fixture holds the oracle's
+        logits of every image, so that set is COMPUTED: F = images with margin <= 2 x (the logit error measured above + half a bf16
+        ulp of the stored logits).  Dense top-1 within F images of the reference's; every candidate's impact within F + 2 images
+        (a candidate run has near-ties of its own); the product's selection == torch.argsort(impact)[:K], and every selected
+        block's REFERENCE impact <= the reference's K-th smallest + 2 (F + 2) images (a theorem given the line before).
+        (First runs on hardware, written against "top-1 within 1 image, impacts within 2": ViT-H/14 15 / 16 and impacts within 2,
+        then 3 after the attention kernel's summation order changed; ViT-L/16 22 / 24 — near-ties, counted below.)"""
     from oracle import ref_cpu
     from ssp2vit import core
     from ssp2vit.engine import VitEngine
@@ -984,13 +990,19 @@ def test_full_depth_large_geometries_vs_reference_golden(gpu, name, tag, layout)
     assert e_small <= tol and e_big <= tol
     assert torch.equal(lg_small, lg_big)
     # stage 2 on the reference's teacher labels (layer-major search: launches of up to (depth + 1) * n images)
+    all_lg = torch.cat([bf16_from_bits(z[f"oracle_logits_bf16bits.{i}"]).float() for i in range(2)])
+    top2 = all_lg.topk(2, dim=-1).values
+    noise = max(e_small, e_big) + 2.0 ** -9 * float(all_lg.abs().max())
+    F = int(((top2[:, 0] - top2[:, 1]) <= 2 * noise).sum())
     base, cand, total = core.depth_search_counts(eng, batches, depth, batch_limit=5, chunk_images=n_all)
-    assert total == n_all and abs(base / n_all - float(z["top1"])) <= 1 / n_all + 1e-9
+    print(f"[{tag}] dense top-1 on the teacher labels: engine {base}/{total}, reference {float(z['top1']) * n_all:.0f}/{n_all}; images on a near-tie "
+          f"(top-2 margin <= {2 * noise:.3f}): F = {F}")
+    assert total == n_all and abs(base - float(z["top1"]) * n_all) <= F + 1e-6
     att = torch.tensor(core.impacts_from_counts(base, cand, total), dtype=torch.float32)
     err = (att.numpy() - z["att_imp"]) * n_all
     print(f"[{tag}] depth importance (images of {n_all}): engine {[round(float(v) * n_all) for v in att]}")
-    print(f"[{tag}]                          reference {[round(float(v) * n_all) for v in z['att_imp']]}; max |diff| {np.abs(err).max():.0f}")
-    assert np.abs(err).max() <= 2 + 1e-6, err
+    print(f"[{tag}]                          reference {[round(float(v) * n_all) for v in z['att_imp']]}; max |diff| {np.abs(err).max():.0f} (allowed {F + 2})")
+    assert np.abs(err).max() <= F + 2 + 1e-6, err
     srt = np.sort(z["att_imp"])
     for p in plans:
         K = p.blocks_to_prune
@@ -999,7 +1011,7 @@ def test_full_depth_large_geometries_vs_reference_golden(gpu, name, tag, layout)
         ref_sel = z[f"s2_selected_k{K}"].tolist()
         worst = max(float(z["att_imp"][b]) for b in sel)
         print(f"[{tag}] K={K}: engine {sel} reference {ref_sel} ({len(set(sel) & set(ref_sel))} in common)")
-        assert worst <= float(srt[K - 1]) + 4 / n_all + 1e-9, (K, sel, worst, float(srt[K - 1]))
+        assert worst <= float(srt[K - 1]) + 2 * (F + 2) / n_all + 1e-9, (K, sel, worst, float(srt[K - 1]))
     eng.close()
 
 
