@@ -895,18 +895,24 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         const int rows_left = g.M - row0 - dr;                       // row a*32 + 8j + dr is valid iff a*32 + 8j < rows_left
         auto voff = [&](int a, int j) -> int { return (a * 32 + 8 * j < rows_left) ? lane_off : 0x7fffffff; };
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-        // cache policy of the x tile (aux operand of the raw-buffer instructions: bit 1 = nt).  GEMM_XNT: 1 = loads non-temporal (the
-        // tile is read once here), 2 = stores, 3 = both — a timing switch of tools/gemm_bench, see DESIGN.md for what it measured
+        // Cache policy of the x tile (aux operand of the raw-buffer instructions: bit 1 = nt).  GEMM_XNT: bit 0 = loads non-temporal,
+        // bit 1 = stores.  Default 1: the tile is READ non-temporally — it is read exactly once here and rewritten.  On launches whose x
+        // exceeds the 256 MiB Infinity Cache (the layer-major search: 630 400 rows = 1.9 GB) that is + 8.8 % on the out-projection
+        // (1131 -> 1040 us sustained), nothing either way at 63 040 rows; non-temporal STORES of x do nothing, both together lose
+        // (profiles/r04_h_resid_policy.jsonl).  Compile time only: a run-time choice between the two load forms spilled 379 registers.
 #ifndef GEMM_XNT
-#define GEMM_XNT 0
+#define GEMM_XNT 1
 #endif
         constexpr int XLD_AUX = (GEMM_XNT & 1) ? 2 : 0, XST_AUX = (GEMM_XNT & 2) ? 2 : 0;
+        auto xload = [&](int vo, int so) __attribute__((always_inline)) -> f32x4 {
+          return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_in, vo, so, XLD_AUX));
+        };
         f32x4 xin[NXB][4];
 #pragma unroll
         for (int p = 0; p < NXB; ++p)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            xin[p][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_in, voff(p >> 1, j), xoff(p >> 1, p & 1, j), XLD_AUX));
+            xin[p][j] = xload(voff(p >> 1, j), xoff(p >> 1, p & 1, j));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -940,7 +946,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0); // hoist these loads to the top and spill their destinations)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              xin[p % NXB][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr_in, voff((p + NXB) >> 1, j), xoff((p + NXB) >> 1, (p + NXB) & 1, j), XLD_AUX));
+              xin[p % NXB][j] = xload(voff((p + NXB) >> 1, j), xoff((p + NXB) >> 1, (p + NXB) & 1, j));
             __builtin_amdgcn_sched_barrier(0);
           }
         }
