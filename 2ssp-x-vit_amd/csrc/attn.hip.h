@@ -32,6 +32,19 @@
 //     half.  Same bits, and 3-5 % SLOWER on the 197-token kernel (tools/attn_bench, 3520 items: 1043-1060 us against 1000-1022 with
 //     the padding computed; profiles/r04_g_attn_ab.txt): the branches cut the one basic block in which hipcc interleaves the
 //     exponentials with the MFMAs of the next phase.  Packing alone: 1000 us against 1008-1022 (+1-2 %).
+// Cache policy A/B switches: K / V are read exactly once per launch (ATTN_NT_KV: their LDS-DMA marked non-temporal), the output
+// is read next by another kernel (ATTN_NT_OUT: non-temporal stores)
+#ifndef ATTN_NT_KV
+#define ATTN_NT_KV 0
+#endif
+#ifndef ATTN_NT_OUT
+#define ATTN_NT_OUT 0
+#endif
+#if ATTN_NT_KV
+#define GLDS_KV glds16_nt
+#else
+#define GLDS_KV glds16
+#endif
 // A/B switches (timing builds of tools/attn_bench only; the product builds with both on)
 #ifndef ATTN_SOFTMAX_PACKED
 #define ATTN_SOFTMAX_PACKED 1
@@ -415,13 +428,13 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
     for (int piece = 0; piece < NT * 4; ++piece) {
       const int row = piece * 8 + (lane >> 3);
       const int rc = row < tokens ? row : tokens - 1;
-      glds16(base + (size_t)rc * ld + dim + ((c ^ ((row >> 1) & 7)) << 3), Kd + piece * 1024);
+      GLDS_KV(base + (size_t)rc * ld + dim + ((c ^ ((row >> 1) & 7)) << 3), Kd + piece * 1024);
     }
 #pragma unroll 4
     for (int piece = 0; piece < NT * 4; ++piece) {
       const int row = piece * 8 + (lane >> 3);
       const int rc = row < tokens ? row : tokens - 1;
-      glds16(base + (size_t)rc * ld + 2 * dim + ((c ^ (((row >> 1) & 1) << 2)) << 3), Vd + piece * 1024);
+      GLDS_KV(base + (size_t)rc * ld + 2 * dim + ((c ^ (((row >> 1) & 1) << 2)) << 3), Vd + piece * 1024);
     }
   };
 
@@ -592,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
       const int qq = wave * 32 + r4 * 8 + (lane >> 3);
-      if (qq < tokens) *(bf16x8*)(out + (r0 + qq) * ldo + head * 64 + (lane & 7) * 8) = ov[r4];
+      if (qq < tokens) { if (ATTN_NT_OUT) __builtin_nontemporal_store(ov[r4], (bf16x8*)(out + (r0 + qq) * ldo + head * 64 + (lane & 7) * 8)); else *(bf16x8*)(out + (r0 + qq) * ldo + head * 64 + (lane & 7) * 8) = ov[r4]; }
     }
   }
 }
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
       piece = piece < NP ? piece : piece - 8;                  // the last round re-sends a piece (same bytes to the same place)
       const int gch = piece * 64 + ls, row = gch / CH, c = gch - row * CH;
       const int rc = row < tokens ? row : tokens - 1;
-      glds16(base + (size_t)rc * ld + c * 8, dst + piece * 1024);
+      GLDS_KV(base + (size_t)rc * ld + c * 8, dst + piece * 1024);
     }
   };
   auto load_q_asm = [&](int it, int qt, bf16x8 (&dst)[KS]) {

@@ -122,8 +122,15 @@ __device__ __forceinline__ void ln_chunk_write(const f32x4& v, float mean, float
   bf16x4 o;
 #pragma unroll
   for (int k = 0; k < 4; ++k) o[k] = (bf16)__builtin_fmaf((v[k] - mean) * rstd, g4[k], b4[k]);
-  if constexpr (OUT8) *(uint32_t*)((uint8_t*)y + c * 4) = pack_e4m3x4_from((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
-  else *(bf16x4*)((bf16*)y + c * 4) = o;
+#ifndef LN_NT_STORES
+#define LN_NT_STORES 0
+#endif
+  if constexpr (OUT8) {
+    const uint32_t pk = pack_e4m3x4_from((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+    if (LN_NT_STORES) __builtin_nontemporal_store(pk, (uint32_t*)((uint8_t*)y + c * 4)); else *(uint32_t*)((uint8_t*)y + c * 4) = pk;
+  } else {
+    if (LN_NT_STORES) __builtin_nontemporal_store(o, (bf16x4*)((bf16*)y + c * 4)); else *(bf16x4*)((bf16*)y + c * 4) = o;
+  }
 }
 // Maximum over the 64 lanes on the VALU (the pattern of wave_sum_dpp).
 __device__ __forceinline__ float wave_max_dpp(float v) {

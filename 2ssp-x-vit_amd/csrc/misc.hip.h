@@ -60,6 +60,10 @@ __global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ 
 // stores are straight-line code.  Round 2 predicated every chunk (`if (chunk < nv)`); for MAXV = 5 the merges of the
 // conditionally loaded row cost 270 register moves and 138 VGPRs — 3 waves per SIMD, 3.1 TB/s on ViT-H/14 against 5.7 for the
 // narrower rows (profiles/r03_d_other_models.jsonl).  The results do not depend on FULL (same ln_row_stats / ln_chunk_write).
+// Cache policy (A/B switches; see DESIGN.md section 6 for what was measured): the fp32 row is read exactly once here
+#ifndef LN_NT_LOADS
+#define LN_NT_LOADS 1
+#endif
 template <int MAXV, bool FULL = false>
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, size_t in_stride,
                                                             const float* __restrict__ gamma,
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   f32x4 v[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
-    if (FULL || i * 64 + lane < nv) v[i] = xr[i * 64 + lane];
+    if (FULL || i * 64 + lane < nv) v[i] = LN_NT_LOADS ? __builtin_nontemporal_load(xr + i * 64 + lane) : xr[i * 64 + lane];
   float mean, rstd;
   ln_row_stats<MAXV, FULL>(v, lane, nv, 1.0f / (float)D, eps, mean, rstd);
   // gamma / beta only now (L2 hits): held across the statistics they cost 8 registers per chunk and most of the eight waves per

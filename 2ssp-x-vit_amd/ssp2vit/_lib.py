@@ -173,11 +173,18 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if _needs_rebuild():
-        if not build_if_missing:
-            raise Ssp2Error(f"{LIB_PATH} missing or stale; run `python -c 'import __graft_entry__ as g; g.build()'`")
-        build_library(only_if_stale=True)
-    lib = C.CDLL(LIB_PATH)
+    variant = os.environ.get("SSP2_LIB_VARIANT")          # A/B runs only (scripts/build_variant.py): lib/libssp2vit_<variant>.so, built with extra -D flags
+    if variant:
+        path = os.path.join(os.path.dirname(LIB_PATH), f"libssp2vit_{variant}.so")
+        if not os.path.exists(path):
+            raise Ssp2Error(f"SSP2_LIB_VARIANT={variant}: {path} does not exist (scripts/build_variant.py builds it)")
+    else:
+        path = LIB_PATH
+        if _needs_rebuild():
+            if not build_if_missing:
+                raise Ssp2Error(f"{LIB_PATH} missing or stale; run `python -c 'import __graft_entry__ as g; g.build()'`")
+            build_library(only_if_stale=True)
+    lib = C.CDLL(path)
     vp, i32, i64p = C.c_void_p, C.c_int, C.POINTER(C.c_int64)
     lib.ssp2_abi_version.restype = i32
     lib.ssp2_last_error.restype = C.c_char_p

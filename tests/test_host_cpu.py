@@ -691,3 +691,36 @@ def test_hf_origin_checkpoint_keeps_eps_and_hook_site_across_prune_export_reload
     sdt = {k: v for k, v in mt.state_dict().items() if not k.startswith("head.")}
     with pytest.raises(AttributeError):
         W.from_state_dict(sdt, {"num_attention_heads": 4})
+
+
+def test_inline_asm_memory_instructions_with_scalar_operands_carry_their_wait_states():
+    """VERDICT r03 item 9 / the round-3 bug: a vector-memory instruction that reads an SGPR a VALU instruction has just written
+    (hipcc reloads spilled scalars with v_readlane_b32) needs five wait states, and hipcc pads only instructions it knows — not
+    inline asm.  Audit, enforced on the sources: every inline-asm statement of csrc/ that holds a memory mnemonic (global_ / buffer_ /
+    flat_ / scratch_ / ds_) AND takes a scalar-register operand (an "s" constraint) must open with `s_nop 4`.  (State of the audit:
+    one such site, the LayerNorm phase's row loads in gemm256.hip.h; every other inline-asm load / store addresses through VGPRs
+    only — `global_load_dwordx4 v, v[addr], off`, `ds_write_* v, v` — and the LDS-DMA pieces and raw-buffer accesses are compiler
+    builtins, whose hazards hipcc handles itself.)"""
+    import re
+    csrc = os.path.join(PKG, "csrc")
+    sites, bad = [], []
+    for root, _, files in os.walk(csrc):
+        for f in files:
+            if not f.endswith((".h", ".hip")):
+                continue
+            src = open(os.path.join(root, f)).read()
+            for m in re.finditer(r'asm\s+volatile\s*\(|asm\s*\(', src):
+                depth, i = 0, m.end() - 1
+                while i < len(src):
+                    depth += src[i] == "("; depth -= src[i] == ")"
+                    if depth == 0:
+                        break
+                    i += 1
+                stmt = src[m.start():i + 1]
+                if re.search(r'"[^"]*(global_|buffer_|flat_|scratch_|ds_)(load|store|read|write|atomic)', stmt) and re.search(r'"=?&?s"\s*\(', stmt):
+                    sites.append((f, stmt[:80]))
+                    text = "".join(re.findall(r'"([^"]*)"', stmt.split(":")[0]))
+                    if not text.lstrip().startswith("s_nop 4"):
+                        bad.append((f, stmt[:120]))
+    assert sites, "the audit pattern no longer finds the known site (gemm256.hip.h LayerNorm phase): fix the pattern"
+    assert not bad, bad
