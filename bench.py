@@ -202,6 +202,112 @@ def roofline_by_family(by_class, precision):
     return out
 
 
+class _PowerSampler:
+    """Card power (uW) and shader clock (Hz) from sysfs every 20 ms, the card picked by the PCI address HIP reports (sysfs lists
+    every card of the host).  Missing files (no sysfs access) simply give None."""
+
+    def __init__(self, dev):
+        import glob
+        import threading
+        cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cards = [c for c in cards if os.path.realpath(c).endswith(addr)] or cards
+        except Exception:
+            pass
+        self.pw, self.ck = [], []
+        for c in cards:
+            for name in ("power1_average", "power1_input"):
+                self.pw += glob.glob(os.path.join(c, "hwmon", "hwmon*", name))
+            self.ck += glob.glob(os.path.join(c, "hwmon", "hwmon*", "freq1_input"))
+        self.rows, self.stop = [], False
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    @staticmethod
+    def _read(files):
+        best = None
+        for f in files:
+            try:
+                v = float(open(f).read().strip())
+                best = v if best is None else max(best, v)
+            except (OSError, ValueError):
+                pass
+        return best
+
+    def _run(self):
+        while not self.stop:
+            self.rows.append((time.time(), self._read(self.pw), self._read(self.ck)))
+            time.sleep(0.02)
+
+    def window(self, t0, t1):
+        rows = [r for r in self.rows if t0 + 0.3 * (t1 - t0) <= r[0] <= t1]          # the settled part of the run
+        pw = [r[1] for r in rows if r[1] is not None]
+        ck = [r[2] for r in rows if r[2] is not None]
+        return {"power_w": round(sum(pw) / len(pw) / 1e6, 1) if pw else None, "sclk_mhz": round(sum(ck) / len(ck) / 1e6, 1) if ck else None}
+
+
+def sustained_families(eng, dev, rows, dim, d_int, seconds=0.8):
+    """what each GEMM family of the step sustains ON ITS OWN — its shape launched back to back for `seconds`
+    through the C ABI's projection operator (ssp2_linear_bf16: the very kernels of the forward), with the card's power and shader
+    clock sampled beside it — and, in the same process on the same box, what AMD's library (hipBLASLt behind
+    torch.nn.functional.linear, bias-only epilogue: it has no fused GELU / fp32-residual form) sustains on that shape: the realistic
+    ceiling of a bf16 GEMM of this shape on this card under its power cap.  Outside the timed region; bf16 only."""
+    import ctypes as C
+    sampler = _PowerSampler(dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    out = {}
+    shapes = (("qkv", rows, 3 * dim, dim, 0, "bias, bf16 out"), ("proj", rows, dim, dim, 1, "bias + fp32 residual"),
+              ("fc1", rows, d_int, dim, 2, "bias + erf-GELU"), ("fc2", rows, dim, d_int, 1, "bias + fp32 residual"))
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for name, M, N, K, epi, what in shapes:
+        a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        npad = (N + 255) // 256 * 256
+        w = torch.zeros(npad, K, device=dev, dtype=torch.bfloat16)
+        w[:N] = ((torch.rand(N, K, device=dev, generator=g) * 2 - 1) * 0.05).to(torch.bfloat16)
+        b = torch.zeros(npad, device=dev, dtype=torch.float32)
+        o = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi != 1 else None
+        x = torch.zeros(M, N, device=dev, dtype=torch.float32) if epi == 1 else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+        def ours():
+            eng.lib.ssp2_linear_bf16(stream, epi, p(a), K, p(w), K, p(b), M, N, K, p(o), N, p(x), N, 2)
+        bl = b[:N].to(torch.bfloat16)
+        lib = lambda: torch.nn.functional.linear(a, w[:N], bl)
+        row = {"shape": [M, N, K], "epilogue": what}
+        for label, fn in (("ours", ours), ("library_bias_only", lib)):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record(); e1.synchronize()
+            n = max(40, int(seconds / (e0.elapsed_time(e1) / 20 * 1e-3)))
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.time()
+            a0.record()
+            for _ in range(n):
+                fn()
+            a1.record(); a1.synchronize()
+            t1 = time.time()
+            us = a0.elapsed_time(a1) / n * 1e3
+            tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
+            w_ = sampler.window(t0, t1)
+            row[label] = {"us": round(us, 1), "tflops": round(tf, 1), **w_,
+                          "tflops_per_kw": round(tf / w_["power_w"] * 1e3, 1) if w_.get("power_w") else None}
+        row["ours_over_library"] = round(row["ours"]["tflops"] / row["library_bias_only"]["tflops"], 3)
+        out[name] = row
+        del a, w, o, x
+        torch.cuda.empty_cache()
+    sampler.stop = True
+    out["note"] = ("each family's shape of the 320-image search chunk, launched back to back for %.1f s (ours: ssp2_linear_bf16 on the persistent 256 x 256 kernel, "
+                   "fused epilogue as in the step; library: hipBLASLt, bias only); power / clock from sysfs, None where it is not readable" % seconds)
+    return out
+
+
 def cpu_budget():
     """(threads to use, facts): the PHYSICAL cores this process may really run on — the smallest of the physical-core count, the
     scheduler affinity mask and the cgroup CPU quota.  Round 3 let PyTorch take every logical CPU of the host (128) on a box whose
@@ -392,6 +498,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=64, help="images per leg (stage-1 scoring / top-1 eval) per pass of the CPU baseline; three passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the per-family sustained / library-ceiling measurement (about 10 s)")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level secondary measurement")
     ap.add_argument("--act-l2-only", action="store_true", help="only the standalone activation-L2 kernel loop (PMC passes)")
     ap.add_argument("--no-batch-candidates", action="store_true",
@@ -692,6 +799,19 @@ def main():
                                               note="one untimed step with HIP events around every launch; `roofline` above is the fc1 family inside the timed region")
         if not args.no_roofline:
             line["act_l2_kernel"] = act_l2_figure(eng, args.batch, tokens, d_int, dev)
+        if families is not None and world == 1 and args.precision == "bf16" and not args.no_sustained:
+            try:
+                sus = sustained_families(eng, dev, eval_chunk * tokens, dim, d_int)
+                line["sustained_by_family"] = sus
+                for fam, keys in (("fc1", ("fc1",)), ("qkv", ("qkv",)), ("resid", ("proj", "fc2"))):     # what VERDICT asks for inside roofline_by_family
+                    if fam in line.get("roofline_by_family", {}):
+                        line["roofline_by_family"][fam]["sustained"] = {k: {"ours_tflops": sus[k]["ours"]["tflops"], "power_w": sus[k]["ours"]["power_w"],
+                                                                               "sclk_mhz": sus[k]["ours"]["sclk_mhz"],
+                                                                               "library_ceiling_tflops": sus[k]["library_bias_only"]["tflops"],
+                                                                               "library_power_w": sus[k]["library_bias_only"]["power_w"],
+                                                                               "library_sclk_mhz": sus[k]["library_bias_only"]["sclk_mhz"]} for k in keys}
+            except Exception as exc:                                     # a yardstick, never a reason to lose the line
+                line["sustained_by_family"] = {"error": repr(exc)[:200]}
         if world == 1 and not args.no_api and args.config == 1 and args.precision == "bf16":
             eng.close(); eng1.close()
             for t in twins:

@@ -18,7 +18,7 @@ timeout -k 10 300 bash scripts/pmc_act_l2.sh > $O/${TAG}_pmc_act_l2.log 2>&1; cp
 cp profiles/${TAG}_pmc_*.json $O/
 timeout -k 10 500 python3 bench.py > $O/${TAG}_bench.jsonl 2> $O/${TAG}_bench.err || exit 1
 cut -c1-300 $O/${TAG}_bench.jsonl
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG} -- python3 bench.py --no-cpu-baseline --no-api --no-overlap-figure > $O/${TAG}_bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG} -- python3 bench.py --no-cpu-baseline --no-api --no-overlap-figure --no-sustained > $O/${TAG}_bench_prof.log 2>&1
 cp $(ls -t $O/prof_${TAG}/*/*_kernel_stats.csv | head -1) $O/${TAG}_bench_kernel_stats.csv
 python3 scripts/trace_gaps.py $(ls -t $O/prof_${TAG}/*/*_kernel_trace.csv | head -1) --json $O/${TAG}_trace_gaps.json > /dev/null 2>&1
 for v in "--host-inputs" "--uint8" "--host-inputs --uint8" "--two-streams"; do
