@@ -402,7 +402,8 @@ __device__ unsigned long long* attn_stamp_ptr;    // [8 waves][256 slots] of wor
 template <int NT>
 __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                                int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
-                                                               int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0) {
+                                                               int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0,
+                                                               unsigned int* __restrict__ sat_counter = nullptr) {
   // out8 (fp8 mode, round 3): the output is ALSO the A operand of an e4m3 out-projection — written as e4m3(o * ATTN_OUT8_SCALE)
   // bytes [rows, ldo8] instead of bf16 (a fixed power-of-two scale: an attention output is a convex combination of V rows, O(0.1-1);
   // x 16 puts it into the upper half of the e4m3 range, the projection's epilogue divides it out exactly)
@@ -565,12 +566,13 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
       // e4m3 bytes: the wave's [32 queries][64 B] tile through its staging area (a lane's four consecutive d_h are one dword), then
       // 128 sixteen-byte row chunks, two per lane
       const float sc8 = inv * ATTN_OUT8_SCALE;
+      bool sat8 = false;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
-          *(uint32_t*)(ost + l31 * 64 + dt * 32 + 8 * g4 + 4 * lh) = pack_e4m3x4_from(oacc[dt][4 * g4] * sc8, oacc[dt][4 * g4 + 1] * sc8,
-                                                                                    oacc[dt][4 * g4 + 2] * sc8, oacc[dt][4 * g4 + 3] * sc8);
+          *(uint32_t*)(ost + l31 * 64 + dt * 32 + 8 * g4 + 4 * lh) = pack_e4m3x4_sat(oacc[dt][4 * g4] * sc8, oacc[dt][4 * g4 + 1] * sc8,
+                                                                                   oacc[dt][4 * g4 + 2] * sc8, oacc[dt][4 * g4 + 3] * sc8, sat8);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       f32x4 o8[2];
 #pragma unroll
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
         const int c = r2 * 64 + lane, qq = wave * 32 + (c >> 2);
         if (qq < tokens) *(f32x4*)(out8 + (r08 + qq) * (size_t)ldo8 + head8 * 64 + (c & 3) * 16) = o8[r2];
       }
+      report_sat(sat8, sat_counter);          // (padding queries repeat the last token's row: they cannot saturate alone)
       continue;
     }
 #pragma unroll
@@ -627,7 +630,8 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
 template <int NT>
 __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                             int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
-                                                            int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0) {
+                                                            int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0,
+                                                            unsigned int* __restrict__ sat_counter = nullptr) {
   static_assert(NT == 9, "waves 0..7 take tiles 0..7; the ninth tile (one query) is split over the waves by key tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DH = 80, KS = 5, DT = 3, CH = 10, NKEY = NT * 32, RSB = 160, KV = NKEY * RSB;     // 46080 B per operand
@@ -722,7 +726,9 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
     if (ls < 40) {
       const size_t row = r0 + (size_t)(tokens - 1);
       if (out8) {
-        const uint32_t pk = pack_e4m3x4_from(o0 * inv * ATTN_OUT8_SCALE, o1 * inv * ATTN_OUT8_SCALE, 0.f, 0.f);
+        bool sat8 = false;
+        const uint32_t pk = pack_e4m3x4_sat(o0 * inv * ATTN_OUT8_SCALE, o1 * inv * ATTN_OUT8_SCALE, 0.f, 0.f, sat8);
+        if (sat8 && sat_counter) atomicAdd(sat_counter, 1u);
         *(uint16_t*)(out8 + row * (size_t)ldo8 + head * DH + d) = (uint16_t)pk;
       } else {
         bf16x2 o2; o2[0] = (bf16)(o0 * inv); o2[1] = (bf16)(o1 * inv);
@@ -804,6 +810,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
         bf16* op = out + (r0 + q) * ldo + head * DH;
         uint8_t* op8 = out8 ? out8 + (r0 + q) * (size_t)ldo8 + head * DH : nullptr;       // fp8 mode: e4m3(o * 16) bytes (see attn64_persist_kernel)
         const float sc8 = inv * ATTN_OUT8_SCALE;
+        bool sat8 = false;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -811,7 +818,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
             const int d0 = dt * 32 + 8 * g4 + 4 * lh;
             if (d0 < DH) {
               if (op8) {
-                *(uint32_t*)(op8 + d0) = pack_e4m3x4_from(oacc[dt][4 * g4] * sc8, oacc[dt][4 * g4 + 1] * sc8, oacc[dt][4 * g4 + 2] * sc8, oacc[dt][4 * g4 + 3] * sc8);
+                *(uint32_t*)(op8 + d0) = pack_e4m3x4_sat(oacc[dt][4 * g4] * sc8, oacc[dt][4 * g4 + 1] * sc8, oacc[dt][4 * g4 + 2] * sc8, oacc[dt][4 * g4 + 3] * sc8, sat8);
               } else {
                 bf16x4 o4;
 #pragma unroll
@@ -820,6 +827,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
               }
             }
           }
+        if (op8) report_sat(sat8, sat_counter);
       }
     };
     // The extra query against this wave's key tile(s): local softmax, partial O -> xpart (see `split9` above)

@@ -85,6 +85,19 @@ __device__ __forceinline__ uint32_t pack_e4m3x4_from(float a, float b, float c, 
   return (uint32_t)w;
 }
 
+// The same, noting in `sat` whether any of the four values lay outside the e4m3 range (|v| > 448: the cast clips it).  The fp8 path's
+// unscaled hand-offs (GELU output -> fc2 operand, attention output x 16 -> out-projection operand) count such events per engine
+// (ssp2_query SSP2_Q_FP8_SATURATED): a checkpoint whose activations leave the range is REPORTED instead of silently clipped.
+__device__ __forceinline__ uint32_t pack_e4m3x4_sat(float a, float b, float c, float d, bool& sat) {
+  const float m = fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d)));
+  sat = sat || (m > 448.f);
+  return pack_e4m3x4_from(a, b, c, d);
+}
+// one wave: if any lane saw a clipped value, lane 0 of the wave adds 1 to *counter (a no-op branch otherwise; counter may be null)
+__device__ __forceinline__ void report_sat(bool sat, unsigned int* counter) {
+  if (counter && __builtin_amdgcn_ballot_w64(sat) != 0 && (threadIdx.x & 63) == 0) atomicAdd(counter, 1u);
+}
+
 // One LayerNorm row, held by ONE wave: lane owns the float4 chunks lane, lane + 64, ... of the row (nv = D / 4 chunks,
 // chunks past nv are skipped).  Two-pass mean / variance in fp32, every multiply-add spelled out, so that the standalone
 // kernel (misc.hip.h) and the LayerNorm phase of the residual GEMM (gemm256.hip.h) produce the same bits from the

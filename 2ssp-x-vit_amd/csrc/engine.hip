@@ -121,6 +121,7 @@ struct ssp2_engine {
   int ln_set = 0;                              // queue-head set of the next fused launch (the launch zeroes the other one)
   int n_xcc_seen = 0;
   bool xcc_ok = false;                         // XCC_ID probe at create: ids 0..7 seen, nothing else (else the fused form stays off)
+  unsigned int* fp8_sat = nullptr;             // device counter of clipped e4m3 casts (SSP2_Q_FP8_SATURATED)
   uint8_t* obuf8 = nullptr;                    // attention output as e4m3(o * 16) bytes: the A operand of the fp8 out-projection (SSP2_OPT_FP8_PROJ)
   int ld8_dim = 0, ld8_int_max = 0;
   float* stage_f32 = nullptr;   // staging buffer of ssp2_load_tensor (host sources)
@@ -342,7 +343,7 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullp
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
       hipLaunchKernelGGL((attn64_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
-                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim);
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim, e->fp8_sat);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -361,7 +362,7 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullp
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
       hipLaunchKernelGGL((attn80_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
-                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim);
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim, e->fp8_sat);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -563,6 +564,15 @@ int ssp2_query(ssp2_handle e, int what) {
     case SSP2_Q_MAX_IMAGES: return e->d.max_images;
     case SSP2_Q_TOKENS: return e->tokens;
     case SSP2_Q_IMG: return e->d.img;
+    case SSP2_Q_FP8_SATURATED:
+    case SSP2_Q_FP8_SATURATED_RESET: {
+      if (!e->fp8_sat) return 0;
+      unsigned int v = 0;
+      if (hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(&v, e->fp8_sat, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(SSP2_EHIP, "reading the fp8 saturation counter failed");
+      if (what == SSP2_Q_FP8_SATURATED_RESET && hipMemset(e->fp8_sat, 0, sizeof(v)) != hipSuccess) return fail(SSP2_EHIP, "resetting the fp8 saturation counter failed");
+      return (int)std::min<unsigned int>(v, 0x7fffffffu);
+    }
     default: return fail(SSP2_EINVAL, "unknown query %d", what);
   }
 }
@@ -692,6 +702,7 @@ int ssp2_set_precision(ssp2_handle e, int mode) {
     if ((rc = dalloc(e, &e->act8, (size_t)e->rows_cap * e->ld8_int_max, true))) return rc;
     if ((rc = dalloc(e, &e->hscale, (size_t)e->rows_cap, true))) return rc;
     if ((rc = dalloc(e, &e->obuf8, (size_t)e->rows_cap * e->ld8_dim, true))) return rc;
+    if ((rc = dalloc(e, &e->fp8_sat, 4, true))) return rc;                   // (zeroed by dalloc)
   }
   e->fp8 = true;
   return 0;

@@ -91,6 +91,15 @@ class VitEngine:
 
     def close(self) -> None:
         if getattr(self, "h", None):
+            if getattr(self, "precision", "bf16") == "fp8":
+                try:                                              # an fp8 engine that clipped attention outputs says so when it goes away
+                    n = self.fp8_saturation()
+                    if n > 0:
+                        import warnings
+                        warnings.warn(f"ssp2vit fp8 engine: {n} wave(s) clipped attention outputs at the e4m3 range (|o| > 28); "
+                                      "use set_option('fp8_proj', 0) or precision='bf16' for this checkpoint", RuntimeWarning, stacklevel=2)
+                except Exception:
+                    pass
             self.lib.ssp2_destroy(self.h)
             self.h = None
 
@@ -132,6 +141,15 @@ class VitEngine:
 
     def get_option(self, name: str) -> int:
         v = self.lib.ssp2_get_option(self.h, OPTIONS[name])
+        if v < 0:
+            check(v)
+        return int(v)
+
+    def fp8_saturation(self, reset: bool = False) -> int:
+        """fp8 mode: how many waves have CLIPPED a value when the attention output was handed to the out-projection as e4m3(o x 16)
+        (|o| > 28) since the engine was built / the counter was reset.  0 for a model whose attention outputs stay in range; > 0
+        says this checkpoint wants `set_option("fp8_proj", 0)` or bf16.  Waits for the stream."""
+        v = self.lib.ssp2_query(self.h, 8 if reset else 7)            # SSP2_Q_FP8_SATURATED_RESET / SSP2_Q_FP8_SATURATED
         if v < 0:
             check(v)
         return int(v)

@@ -793,6 +793,8 @@ def main():
                                 "flops_per_launch_avg": prof.flops / prof.launches,
                                 "library_yardstick": library_yardstick("fc1") if args.precision == "bf16" and args.model == "vit_base_patch16_224" else None,
                                 "shapes": f"[{eng.rows(min(n_calib, calib_chunk), args.batch)} | {eval_chunk * tokens} | {eval_chunk}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk{lm} | CLS tail)"}
+        if args.precision == "fp8":
+            line["fp8_saturation_events"] = eng.fp8_saturation()       # waves that clipped an attention output at the e4m3 range (0 = none)
         if families is not None:
             dom = max((k for k in families if k != "other"), key=lambda k: families[k]["ms"])
             line["roofline_by_family"] = dict(families, time_dominant=dom,

@@ -237,7 +237,14 @@ int ssp2_profile_query(ssp2_handle h, int klass, double* total_ms, int64_t* laun
 int ssp2_profile_end(ssp2_handle h, double* total_ms, int64_t* launches, double* gemm_flops);
 
 /* workspace / capacity queries */
-enum { SSP2_Q_DIM = 0, SSP2_Q_DEPTH, SSP2_Q_CLASSES, SSP2_Q_SCORE_LD /* max ceil64(d_int) */, SSP2_Q_MAX_IMAGES, SSP2_Q_TOKENS, SSP2_Q_IMG };
+/* SSP2_Q_FP8_SATURATED (fp8 mode): how many waves have clipped a value at the e4m3 range in the attention output's hand-off to the
+ * out-projection — it is written as e4m3(o x 16), so |o| > 28 clips — since the handle was created or the counter was last read with
+ * SSP2_Q_FP8_SATURATED_RESET (which returns the count and zeroes it).  Synchronises the handle's stream.  0 on a model whose
+ * attention outputs stay in range; > 0 means: run that checkpoint with SSP2_OPT_FP8_PROJ = 0 (or in bf16).  (The LayerNorm outputs
+ * carry per-row scales and cannot clip; the GELU output that fc2 reads is cast unscaled and NOT counted — it clips beyond 448, and
+ * counting in that epilogue costs the fc1 kernels the registers they do not have: 20-188 spilled bytes per lane when it was tried.) */
+enum { SSP2_Q_DIM = 0, SSP2_Q_DEPTH, SSP2_Q_CLASSES, SSP2_Q_SCORE_LD /* max ceil64(d_int) */, SSP2_Q_MAX_IMAGES, SSP2_Q_TOKENS, SSP2_Q_IMG,
+       SSP2_Q_FP8_SATURATED, SSP2_Q_FP8_SATURATED_RESET };
 int ssp2_query(ssp2_handle h, int what);                                  /* >= 0, or SSP2_EINVAL */
 int ssp2_tokens(ssp2_handle h);
 size_t ssp2_workspace_bytes(ssp2_handle h);

@@ -1452,6 +1452,51 @@ def test_fp8_engine_tracks_the_bf16_engine_within_the_e4m3_tolerance(gpu, cfg):
     ref.close(); f8.close()
 
 
+@pytest.mark.parametrize("cfg", ["vit_small_patch16_224_d2", "vit_huge_patch14_224_d2"])
+def test_fp8_attention_output_saturation_is_counted_and_the_bf16_projection_stays_in_tolerance(gpu, cfg):
+    """in fp8 mode the attention output reaches the out-projection as e4m3(o x 16) — a fixed scale, so |o| > 28 is clipped.
+    Round 3 clipped silently; now the persistent attention kernels (d_h = 64 and d_h = 80, incl. the split 257th query) count the
+    waves that clipped (ssp2_query SSP2_Q_FP8_SATURATED, VitEngine.fp8_saturation) and an engine that did so warns when it is closed.
+      * ordinary weights (V ~ O(1)): the counter stays 0
+      * V projection scaled x 300 (|o| far beyond 28): the counter is > 0 with the e4m3 out-projection; with set_option("fp8_proj", 0)
+        — the remedy the warning names — it stays 0 and the logits are back inside the e4m3 tolerance of the bf16 engine (rel L2 <= 0.15)."""
+    import warnings
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights(cfg, classes=10, seed=8, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
+    g = torch.Generator().manual_seed(4)
+    px = torch.randn(32, 3, 224, 224, generator=g).to(gpu)
+    f8 = VitEngine(w, max_images=32, precision="fp8")
+    f8.forward_logits(px)
+    assert f8.fp8_saturation() == 0
+    f8.close()
+    big = dict(w)
+    D = int(w["dim"])
+    for l in range(int(w["depth"])):
+        q = w[f"qkv_w.{l}"].clone(); q[2 * D:] *= 300.0; big[f"qkv_w.{l}"] = q
+        big[f"proj_w.{l}"] = w[f"proj_w.{l}"] / 300.0                       # keeps the block's output in its usual range
+    ref = VitEngine(big, max_images=32)
+    lr = ref.forward_logits(px).cpu()
+    f8 = VitEngine(big, max_images=32, precision="fp8")
+    l_clip = f8.forward_logits(px).cpu()
+    n_clip = f8.fp8_saturation(reset=True)
+    assert n_clip > 0 and f8.fp8_saturation() == 0
+    f8.set_option("fp8_proj", 0)
+    l_ok = f8.forward_logits(px).cpu()
+    assert f8.fp8_saturation() == 0
+    rel_clip, rel_ok = float((l_clip - lr).norm() / lr.norm()), float((l_ok - lr).norm() / lr.norm())
+    print(f"\n[fp8-saturation] {cfg}: {n_clip} waves clipped with the e4m3 out-projection (logits rel L2 err {rel_clip:.3f}); "
+          f"bf16 out-projection: 0 clipped, rel L2 err {rel_ok:.4f}")
+    assert rel_ok <= 0.15, rel_ok
+    f8.set_option("fp8_proj", 1)
+    f8.forward_logits(px)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        f8.close()
+    assert any("clipped attention outputs" in str(r.message) for r in rec)
+    ref.close()
+
+
 @pytest.mark.parametrize("cfg,layout", [("vit_small_patch16_224_d2", "timm"), ("vit_huge_patch14_224_d2", "timm"), ("vit_large_patch16_224_d2", "hf")])
 def test_fp8_engine_vs_the_cpu_oracle_directly(gpu, cfg, layout):
     """precision="fp8" against the ORACLE (oracle/ref_cpu.py: PyTorch CPU bf16 autocast, pinned to the real reference), not against
