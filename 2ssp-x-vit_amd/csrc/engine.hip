@@ -1165,6 +1165,7 @@ int ssp2_linear_bf16(void* hip_stream, int epilogue, const uint16_t* a_dev, int 
   e.stream = (hipStream_t)hip_stream; e.n_cu = n_cu; e.dev = cur_device();
   e.opt[SSP2_OPT_BIG_TILES] = e.opt[SSP2_OPT_FC1_BIG_TILES] = 1;
   e.opt[SSP2_OPT_BIG_TILE_MIN_ROWS] = kBigTileMinRowsDefault;
+  { const char* v = getenv("SSP2_NT_STORES"); e.opt[SSP2_OPT_NT_STORES] = (v && *v) ? atoi(v) : 1; }      // the forward's default store policy
   GemmArgs g{};
   g.A = (const bf16*)a_dev; g.lda = lda; g.W = (const bf16*)w_dev; g.ldw = ldw; g.bias = bias_dev;
   g.M = M; g.N = N; g.K = K; g.tiles_n = ceil_to(N, 256) / GEMM_BN;
