@@ -1647,6 +1647,14 @@ def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_
     eng.set_option("ln_fusion", 1)                                      # the other spelling of "on": same bits again
     for a, b in zip(plain, run()):
         assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+    if n_img == 40 and precision == "bf16":
+        # the fused form keeps EIGHT per-XCD tile queues, each drained only by workgroups on that XCD.  With the grids capped at
+        # four workgroups (ssp2_set_cu_limit) four XCDs would get none and their panels would be neither multiplied nor normalised —
+        # ln_fusable now refuses such launches (all eight XCC ids seen AND >= 64 workgroups) and the standalone kernel runs: same bits, no hang
+        eng.set_cu_limit(4)
+        for a, b in zip(plain, run()):
+            assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+        eng.set_cu_limit(0)
 
 
 def test_zigzag_launch_order_does_not_change_a_bit(gpu, monkeypatch):
