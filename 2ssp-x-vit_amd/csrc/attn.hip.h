@@ -16,7 +16,8 @@
 #include <type_traits>
 #include "common.hip.h"
 
-#define ATTN_OUT8_SCALE 16.0f        // fp8 mode: attention outputs are written as e4m3(o * 16); the out-projection multiplies by 1 / 16
+#define ATTN_OUT8_SCALE 16.0f        // fp8 mode, default: attention outputs are written as e4m3(o * 16) and the out-projection multiplies by 1 / 16;
+                                     // a calibrated engine passes its own power of two per layer (kernel argument out8_scale, ssp2_fp8_calibrate_*)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Softmax numerators of one 32-query tile, in place, shared by every attention kernel of this file (so they stay bit-identical
@@ -403,7 +404,7 @@ template <int NT>
 __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                                int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
                                                                int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0,
-                                                               unsigned int* __restrict__ sat_counter = nullptr) {
+                                                               unsigned int* __restrict__ sat_counter = nullptr, float out8_scale = ATTN_OUT8_SCALE) {
   // out8 (fp8 mode, round 3): the output is ALSO the A operand of an e4m3 out-projection — written as e4m3(o * ATTN_OUT8_SCALE)
   // bytes [rows, ldo8] instead of bf16 (a fixed power-of-two scale: an attention output is a convex combination of V rows, O(0.1-1);
   // x 16 puts it into the upper half of the e4m3 range, the projection's epilogue divides it out exactly)
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
     if (out8) {
       // e4m3 bytes: the wave's [32 queries][64 B] tile through its staging area (a lane's four consecutive d_h are one dword), then
       // 128 sixteen-byte row chunks, two per lane
-      const float sc8 = inv * ATTN_OUT8_SCALE;
+      const float sc8 = inv * out8_scale;
       bool sat8 = false;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
@@ -631,7 +632,7 @@ template <int NT>
 __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                             int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
                                                             int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0,
-                                                            unsigned int* __restrict__ sat_counter = nullptr) {
+                                                            unsigned int* __restrict__ sat_counter = nullptr, float out8_scale = ATTN_OUT8_SCALE) {
   static_assert(NT == 9, "waves 0..7 take tiles 0..7; the ninth tile (one query) is split over the waves by key tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DH = 80, KS = 5, DT = 3, CH = 10, NKEY = NT * 32, RSB = 160, KV = NKEY * RSB;     // 46080 B per operand
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
       const size_t row = r0 + (size_t)(tokens - 1);
       if (out8) {
         bool sat8 = false;
-        const uint32_t pk = pack_e4m3x4_sat(o0 * inv * ATTN_OUT8_SCALE, o1 * inv * ATTN_OUT8_SCALE, 0.f, 0.f, sat8);
+        const uint32_t pk = pack_e4m3x4_sat(o0 * inv * out8_scale, o1 * inv * out8_scale, 0.f, 0.f, sat8);
         if (sat8 && sat_counter) atomicAdd(sat_counter, 1u);
         *(uint16_t*)(out8 + row * (size_t)ldo8 + head * DH + d) = (uint16_t)pk;
       } else {
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
       if (q < tokens) {
         bf16* op = out + (r0 + q) * ldo + head * DH;
         uint8_t* op8 = out8 ? out8 + (r0 + q) * (size_t)ldo8 + head * DH : nullptr;       // fp8 mode: e4m3(o * 16) bytes (see attn64_persist_kernel)
-        const float sc8 = inv * ATTN_OUT8_SCALE;
+        const float sc8 = inv * out8_scale;
         bool sat8 = false;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)

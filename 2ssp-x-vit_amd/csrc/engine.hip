@@ -82,6 +82,7 @@ struct Layer {
   Mat qkv, proj, fc1, fc2;
   int d_int = 0, ld_int = 0;
   bool attn_dropped = false;   // ssp2_drop_attention: bypass for good
+  float o8_scale = ATTN_OUT8_SCALE;   // fp8 mode: the attention output of this block is handed to the out-projection as e4m3(o * o8_scale)
   int* keep_dev = nullptr;     // ssp2_prune_ffn_into: the kept-neuron list on the device
 };
 
@@ -122,6 +123,8 @@ struct ssp2_engine {
   int n_xcc_seen = 0;
   bool xcc_ok = false;                         // XCC_ID probe at create: ids 0..7 seen, nothing else (else the fused form stays off)
   unsigned int* fp8_sat = nullptr;             // device counter of clipped e4m3 casts (SSP2_Q_FP8_SATURATED)
+  unsigned int* attn_amax = nullptr;           // fp8 calibration: [depth] float bits of max |attention output| per block (ssp2_fp8_calibrate_*)
+  bool fp8_calibrating = false;
   uint8_t* obuf8 = nullptr;                    // attention output as e4m3(o * 16) bytes: the A operand of the fp8 out-projection (SSP2_OPT_FP8_PROJ)
   int ld8_dim = 0, ld8_int_max = 0;
   float* stage_f32 = nullptr;   // staging buffer of ssp2_load_tensor (host sources)
@@ -315,7 +318,7 @@ static int launch_ln(ssp2_engine* e, const float* x, size_t in_stride, const flo
 }
 
 template <int DH, int NT, bool CLS>
-static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullptr) {
+static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullptr, float out8_scale = ATTN_OUT8_SCALE) {
   // d_h = 64: 128-byte K and V rows (LDS-DMA staging) + 4 KiB per wave of output staging; else padded rows
   // d_h = 80 with a whole number of 1-KiB DMA pieces: 160-byte rows + 64 bytes of slack behind V (attn.hip.h)
   constexpr int smem = DH == 64 ? NT * 32 * 256 + 4 * 4096
@@ -343,7 +346,7 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullp
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
       hipLaunchKernelGGL((attn64_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
-                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim, e->fp8_sat);
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim, e->fp8_sat, out8_scale);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -362,7 +365,7 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullp
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
       hipLaunchKernelGGL((attn80_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
-                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim, e->fp8_sat);
+                         e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim, e->fp8_sat, out8_scale);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -383,9 +386,9 @@ static bool attn_persistent(const ssp2_engine* e) {
   const int nt = (e->tokens + 31) / 32;
   return e->opt[SSP2_OPT_ATTN_PERSIST] && ((e->dh == 64 && nt >= 4 && nt <= 7) || (e->dh == 80 && nt == 9 && e->tokens == 257));
 }
-static int launch_attn(ssp2_engine* e, int n, RowMap rm, bool cls_only = false, uint8_t* out8 = nullptr) {
+static int launch_attn(ssp2_engine* e, int n, RowMap rm, bool cls_only = false, uint8_t* out8 = nullptr, float out8_scale = ATTN_OUT8_SCALE) {
   const int nt = (e->tokens + 31) / 32;
-#define ATTN_CASE(DH_, NT_) if (e->dh == DH_ && nt == NT_) return cls_only ? launch_attn_t<DH_, NT_, true>(e, n, rm) : launch_attn_t<DH_, NT_, false>(e, n, rm, out8)
+#define ATTN_CASE(DH_, NT_) if (e->dh == DH_ && nt == NT_) return cls_only ? launch_attn_t<DH_, NT_, true>(e, n, rm) : launch_attn_t<DH_, NT_, false>(e, n, rm, out8, out8_scale)
   ATTN_CASE(64, 7);   // 224/16: 197 tokens (Ti/S/B/L)
   ATTN_CASE(80, 9);   // 224/14: 257 tokens (H/14)
   ATTN_CASE(16, 1);   // reference smoke config: 32/16, 5 tokens
@@ -529,6 +532,41 @@ int ssp2_destroy(ssp2_handle e) {
 int ssp2_set_stream(ssp2_handle e, void* s) {
   if (!e) return fail(SSP2_EINVAL, "null handle");
   e->stream = (hipStream_t)s;
+  return 0;
+}
+
+int ssp2_fp8_calibrate_begin(ssp2_handle e) {
+  if (!e) return fail(SSP2_EINVAL, "null handle");
+  if (!e->fp8 || !e->attn_amax) return fail(SSP2_ESTATE, "fp8 calibration needs ssp2_set_precision(h, SSP2_PREC_FP8) first");
+  HIPCHK(hipMemsetAsync(e->attn_amax, 0, (size_t)e->d.depth * 4, e->stream));
+  e->fp8_calibrating = true;
+  return 0;
+}
+int ssp2_fp8_calibrate_end(ssp2_handle e, float headroom) {
+  if (!e) return fail(SSP2_EINVAL, "null handle");
+  if (!e->fp8_calibrating) return fail(SSP2_ESTATE, "ssp2_fp8_calibrate_end without ssp2_fp8_calibrate_begin");
+  e->fp8_calibrating = false;
+  if (!(headroom >= 1.0f)) headroom = 1.0f;
+  std::vector<float> amax(e->d.depth, 0.f);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(amax.data(), e->attn_amax, (size_t)e->d.depth * 4, hipMemcpyDeviceToHost));
+  for (int l = 0; l < e->d.depth; ++l) {
+    if (!(amax[l] > 0.f) || !std::isfinite(amax[l])) continue;                 // block not seen (skipped / dropped attention): keeps its scale
+    int ex = (int)floorf(log2f(448.0f / (amax[l] * headroom)));
+    ex = std::max(-8, std::min(10, ex));
+    e->layers[l].o8_scale = ldexpf(1.0f, ex);
+  }
+  return 0;
+}
+float ssp2_fp8_attn_scale(ssp2_handle e, int layer) {
+  if (!e || layer < 0 || layer >= e->d.depth) return 0.f;
+  return e->layers[layer].o8_scale;
+}
+int ssp2_fp8_set_attn_scale(ssp2_handle e, int layer, float scale) {
+  if (!e || layer < 0 || layer >= e->d.depth) return fail(SSP2_EINVAL, "bad layer");
+  int ex = 0;
+  if (!(scale > 0.f) || frexpf(scale, &ex) != 0.5f) return fail(SSP2_EINVAL, "the scale must be a power of two > 0 (got %g)", scale);
+  e->layers[layer].o8_scale = scale;
   return 0;
 }
 
@@ -703,6 +741,7 @@ int ssp2_set_precision(ssp2_handle e, int mode) {
     if ((rc = dalloc(e, &e->hscale, (size_t)e->rows_cap, true))) return rc;
     if ((rc = dalloc(e, &e->obuf8, (size_t)e->rows_cap * e->ld8_dim, true))) return rc;
     if ((rc = dalloc(e, &e->fp8_sat, 4, true))) return rc;                   // (zeroed by dalloc)
+    if ((rc = dalloc(e, &e->attn_amax, (size_t)e->d.depth, true))) return rc;
   }
   e->fp8 = true;
   return 0;
@@ -821,14 +860,20 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
       h_ready = false;
       // fp8 out-projection (SSP2_OPT_FP8_PROJ): the persistent attention kernel writes e4m3(o * 16) bytes, the projection runs on
       // e4m3 operands and divides the 16 out in its epilogue
-      const bool f8_proj = f8 && e->opt[SSP2_OPT_FP8_PROJ] && attn_persistent(e) && L.proj.w8 && D % 64 == 0;
-      if ((rc = launch_attn(e, n, rm, false, f8_proj ? e->obuf8 : nullptr))) return rc;
+      // (during ssp2_fp8_calibrate_* the projection stays on bf16 and the block's max |o| is recorded)
+      const bool f8_proj = f8 && e->opt[SSP2_OPT_FP8_PROJ] && attn_persistent(e) && L.proj.w8 && D % 64 == 0 && !e->fp8_calibrating;
+      if ((rc = launch_attn(e, n, rm, false, f8_proj ? e->obuf8 : nullptr, L.o8_scale))) return rc;
+      if (f8 && e->fp8_calibrating && e->attn_amax) {
+        ProfScope ps(e, SSP2_K_OTHER);
+        hipLaunchKernelGGL(absmax_bf16_kernel, dim3(1024), dim3(256), 0, e->stream, e->obuf, (long)M, D, D, e->attn_amax + l);
+        HIPCHK(hipGetLastError());
+      }
       GemmArgs p{};
       p.bias = L.proj.b;
       p.M = M; p.N = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = x; p.ldx = D; p.xin = xsrc;
       if (f8_proj) {
         p.A = (const bf16*)e->obuf8; p.lda = e->ld8_dim; p.W = (const bf16*)L.proj.w8; p.ldw = L.proj.ld8; p.K = e->ld8_dim; p.wscale = L.proj.wscale;
-        p.ascale_const = 1.0f / ATTN_OUT8_SCALE;
+        p.ascale_const = 1.0f / L.o8_scale;
       } else {
         p.A = e->obuf; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.K = D;
       }
@@ -1113,6 +1158,7 @@ int ssp2_clone_weights(ssp2_handle dst, ssp2_handle src) {
     for (int i = 0; i < 4; ++i) d.ln_set[i] = s.ln_set[i];
     if ((rc = copy_mat(dst, d.qkv, s.qkv)) || (rc = copy_mat(dst, d.proj, s.proj))) return rc;
     d.attn_dropped = s.attn_dropped;
+    d.o8_scale = s.o8_scale;
     if (d.d_int == s.d_int) { if ((rc = copy_mat(dst, d.fc1, s.fc1)) || (rc = copy_mat(dst, d.fc2, s.fc2))) return rc; }
     else {   // the FFN arrives through ssp2_prune_ffn_into; fc2's bias does not depend on the kept neurons
       HIPCHK(hipMemcpyAsync(d.fc2.b, s.fc2.b, (size_t)d.fc2.rows_pad * 4, hipMemcpyDeviceToDevice, dst->stream));

@@ -389,3 +389,19 @@ __global__ __launch_bounds__(256) void quant_rows_e4m3_kernel(const bf16* __rest
   }
   if (lane == 0) scale[row] = sc;
 }
+
+// ------------------------------------------------------------------------------------------------
+// fp8 calibration (ssp2_fp8_calibrate_*): largest |value| of a bf16 matrix [rows, cols] (leading dimension ld) -> atomicMax on the bits of
+// a non-negative float (*amax_bits; non-negative floats order as unsigned integers).
+__global__ void absmax_bf16_kernel(const bf16* __restrict__ a, long rows, int cols, int ld, unsigned int* __restrict__ amax_bits) {
+  float m = 0.f;
+  const long n8 = rows * (cols / 8);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / (cols / 8); const int c = (int)(i - r * (cols / 8));
+    const bf16x8 v = *(const bf16x8*)(a + r * ld + c * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf((float)v[k]));
+  }
+  m = wave_max_dpp(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __builtin_bit_cast(unsigned int, m));
+}

@@ -22,6 +22,7 @@ SYMBOLS = [
     "ssp2_prune_ffn_into", "ssp2_set_precision", "ssp2_set_cu_limit", "ssp2_set_option", "ssp2_get_option", "ssp2_profile_query",
     "ssp2_embed", "ssp2_layers", "ssp2_layers_from", "ssp2_head", "ssp2_tail", "ssp2_tail_slots", "ssp2_prune_ffn", "ssp2_drop_attention", "ssp2_d_int", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
     "ssp2_tokens", "ssp2_rows", "ssp2_workspace_bytes", "ssp2_preproc_create", "ssp2_preproc_run", "ssp2_preproc_destroy",
+    "ssp2_fp8_calibrate_begin", "ssp2_fp8_calibrate_end", "ssp2_fp8_attn_scale", "ssp2_fp8_set_attn_scale",
 ]
 
 T_KINDS = ["patch_w", "patch_b", "cls", "pos", "ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
@@ -218,6 +219,11 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_query.argtypes = [vp, i32]
     lib.ssp2_set_precision.argtypes = [vp, i32]
     lib.ssp2_set_cu_limit.argtypes = [vp, i32]
+    lib.ssp2_fp8_calibrate_begin.argtypes = [vp]
+    lib.ssp2_fp8_calibrate_end.argtypes = [vp, C.c_float]
+    lib.ssp2_fp8_attn_scale.argtypes = [vp, i32]
+    lib.ssp2_fp8_attn_scale.restype = C.c_float
+    lib.ssp2_fp8_set_attn_scale.argtypes = [vp, i32, C.c_float]
     lib.ssp2_workspace_bytes.argtypes = [vp]
     lib.ssp2_workspace_bytes.restype = C.c_size_t
     lib.ssp2_preproc_create.argtypes = [i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(vp)]
@@ -225,7 +231,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.ssp2_preproc_destroy.argtypes = [vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("ssp2_last_error", "ssp2_workspace_bytes", "ssp2_rows"):
+        if name not in ("ssp2_last_error", "ssp2_workspace_bytes", "ssp2_rows", "ssp2_fp8_attn_scale"):
             fn.restype = i32
     _lib = lib
     return lib

@@ -145,6 +145,21 @@ class VitEngine:
             check(v)
         return int(v)
 
+    def calibrate_fp8(self, pixels: torch.Tensor, headroom: float = 4.0) -> List[float]:
+        """fp8 mode: measure the attention outputs of `pixels` (one or more chunks of <= max_images images, each launch >= 4096 token
+        rows) with the out-projection on bf16 and set every block's hand-off scale to the largest power of two that keeps
+        max|o| x headroom inside the e4m3 range (ssp2_fp8_calibrate_*).  Explicit and deterministic: only these images count.
+        Returns the scales in force afterwards, one per block (16.0 = the uncalibrated default)."""
+        if self.precision != "fp8":
+            raise Ssp2Error("calibrate_fp8 needs precision='fp8'")
+        self._bind_stream()
+        check(self.lib.ssp2_fp8_calibrate_begin(self.h))
+        try:
+            self.forward_logits(pixels)
+        finally:
+            check(self.lib.ssp2_fp8_calibrate_end(self.h, float(headroom)))
+        return [float(self.lib.ssp2_fp8_attn_scale(self.h, l)) for l in range(self.depth)]
+
     def fp8_saturation(self, reset: bool = False) -> int:
         """fp8 mode: how many waves have CLIPPED a value when the attention output was handed to the out-projection as e4m3(o x 16)
         (|o| > 28) since the engine was built / the counter was reset.  0 for a model whose attention outputs stay in range; > 0

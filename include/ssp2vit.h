@@ -119,6 +119,19 @@ int ssp2_load_tensor_dev(ssp2_handle h, int kind, int layer, const float* dev_pt
  * Call after the weights are loaded; synchronous with respect to later launches on the handle's stream. */
 enum { SSP2_PREC_BF16 = 0, SSP2_PREC_FP8 = 1 };
 int ssp2_set_precision(ssp2_handle h, int mode);
+/* fp8 mode, optional CALIBRATION of the one hand-off that carries a fixed scale: the attention output reaches the e4m3 out-projection as
+ * e4m3(o x s_l), s_l = 16 by default (fine for |o| <= 28; beyond that values clip — counted by SSP2_Q_FP8_SATURATED).
+ *   ssp2_fp8_calibrate_begin(h)          from now on forwards run the out-projection on bf16 and record max |o| per block
+ *   ... one or more ssp2_layers / forward calls over representative images (launches of >= SSP2_OPT_BIG_TILE_MIN_ROWS rows) ...
+ *   ssp2_fp8_calibrate_end(h, headroom)  sets s_l = the largest power of two with  max|o|_l x headroom x s_l <= 448  for every block that
+ *                                        was seen (2^-8 <= s_l <= 2^10; others keep 16), switches the recording off; synchronises
+ *   ssp2_fp8_attn_scale(h, l)            the scale in force for block l (e.g. to store it with a checkpoint); ssp2_fp8_set_attn_scale
+ *                                        sets it directly (a power of two > 0)
+ * Explicit and deterministic: the scales depend only on the images handed over between begin and end, never on launch order. */
+int ssp2_fp8_calibrate_begin(ssp2_handle h);
+int ssp2_fp8_calibrate_end(ssp2_handle h, float headroom);
+float ssp2_fp8_attn_scale(ssp2_handle h, int layer);                     /* > 0, or 0 on a bad argument */
+int ssp2_fp8_set_attn_scale(ssp2_handle h, int layer, float scale);
 
 /* Row layout of the token matrix x.  group <= 0 or >= n: images contiguous, ssp2_rows = n*N.  0 < group < n: SLABS of
  * `group` images (one dataloader batch each), every slab padded to a multiple of 256 rows — a sample then sits at the
