@@ -181,11 +181,22 @@ class VitEngine:
         """Stage-1 + stage-2 APPLY (reference src/vit_pruning.py:297-311 and :499-504) into `twin`, leaving this dense
         engine untouched: kept FFN neurons of every block are gathered in HBM, the chosen blocks lose their attention.
         Asynchronous on the current stream.  masks[l][j] == 1 -> neuron j of block l is pruned."""
+        self.apply_ffn_into(twin, masks)
+        return self.apply_attention_into(twin, drop_blocks)
+
+    def apply_ffn_into(self, twin: "VitEngine", masks: Sequence[Sequence[int]]) -> "VitEngine":
+        """The width half of `apply_into` (a8): the gathers are ENQUEUED on the current stream and do not depend on the depth search, so
+        a caller that has the masks before the search has finished can queue them behind it and spare the GPU the host's latency
+        at the end of the prune (bench.py does)."""
         twin._bind_stream()
         for l, m in enumerate(masks):
             keep = m if isinstance(m, torch.Tensor) else torch.as_tensor(m)
             keep = torch.nonzero(keep == 0).view(-1).to(torch.int32).contiguous()
             check(self.lib.ssp2_prune_ffn_into(twin.h, self.h, l, C.cast(keep.data_ptr(), C.POINTER(C.c_int32)), keep.numel()))
+        return twin
+
+    def apply_attention_into(self, twin: "VitEngine", drop_blocks: Sequence[int]) -> "VitEngine":
+        """The depth half (a9): host-side flags only, no device work."""
         drop = set(int(b) for b in drop_blocks)
         for l in range(self.depth):
             if l in drop or self.absent[l]:

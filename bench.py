@@ -671,6 +671,8 @@ def main():
                 m = torch.ones(imp.numel(), dtype=torch.int16); m[keep] = 0
                 masks.append(m)
             all_masks.append(masks)
+        for masks, twin in zip(all_masks, twins):                          # a8 apply: the gathers into the pruned twin do not depend on the search —
+            eng.apply_ffn_into(twin, masks)                                 # queued behind it NOW, so the prune does not end on the host's latency
         base, cand, total = search()
         impact = torch.tensor(core.impacts_from_counts(base, cand, total), dtype=torch.float32)
         if sd is not None:
@@ -678,7 +680,7 @@ def main():
         chosen = []
         for p, masks, twin in zip(plans, all_masks, twins):
             blocks = sorted(int(i) for i in torch.argsort(impact)[: p.blocks_to_prune])   # a9 (auto_2ssp.py:857)
-            eng.apply_into(twin, masks, blocks)                            # a8 + a9 apply: gathers into the pruned twin
+            eng.apply_attention_into(twin, blocks)                         # a9 apply: the chosen blocks lose their attention (flags)
             chosen.append(blocks)
         return imps, impact, all_masks, chosen
 
