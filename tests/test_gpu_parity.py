@@ -1706,6 +1706,15 @@ def test_zigzag_launch_order_does_not_change_a_bit(gpu, monkeypatch):
     for x, y, z in zip(a, b, c):
         assert torch.equal(x, y) and torch.equal(x, z)
     assert ca == cb == cc
+    # round 4: the store policy of the 256 x 256 GEMM's activation outputs (SSP2_OPT_NT_STORES, default non-temporal) is a cache hint,
+    # never a result: ordinary stores give the same bits
+    assert eng.get_option("nt_stores") == 1
+    eng.set_option("nt_stores", 0)
+    d, cd = run()
+    eng.set_option("nt_stores", 1)
+    for x, y in zip(a, d):
+        assert torch.equal(x, y)
+    assert ca == cd
 
 
 def test_scores_only_forward_stops_behind_the_last_hooked_activation_with_the_same_scores(gpu):
