@@ -104,8 +104,9 @@ def run_one(args, target, run_id):
         test_loader, cal_loader = synthetic_loaders(model, img, args.batch_size, args.synthetic_calib, max(args.eval_batches, 1),
                                                     args.seed + 1, device)
     if rank0:
+        bs = getattr(cal_loader, "batch_size", args.batch_size)            # local data: the reference's loaders fix 64 (:346-347)
         print(f"[INFO] Using device: {device}; model={name}; data={dataset_desc}; calib batches={len(cal_loader)} eval batches={len(test_loader)} "
-              f"of {args.batch_size}; ranks={1 if pg is None else torch.distributed.get_world_size()}")
+              f"of {bs} (this rank's); ranks={1 if pg is None else torch.distributed.get_world_size()}")
 
     params_before = vp.count_total_params(model)
     latency_baseline = measure_latency(model, device, img_size=img)

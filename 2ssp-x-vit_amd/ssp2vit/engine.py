@@ -96,8 +96,9 @@ class VitEngine:
                     n = self.fp8_saturation()
                     if n > 0:
                         import warnings
-                        warnings.warn(f"ssp2vit fp8 engine: {n} wave(s) clipped attention outputs at the e4m3 range (|o| > 28); "
-                                      "use set_option('fp8_proj', 0) or precision='bf16' for this checkpoint", RuntimeWarning, stacklevel=2)
+                        warnings.warn(f"ssp2vit fp8 engine: {n} wave(s) clipped attention outputs at the e4m3 range of their hand-off scale "
+                                      "(|o| > 28 uncalibrated); use calibrate_fp8(...), set_option('fp8_proj', 0) or precision='bf16' for this "
+                                      "checkpoint", RuntimeWarning, stacklevel=2)
                 except Exception:
                     pass
             self.lib.ssp2_destroy(self.h)
