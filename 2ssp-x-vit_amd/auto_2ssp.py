@@ -108,6 +108,24 @@ def run_one(args, target, run_id):
         print(f"[INFO] Using device: {device}; model={name}; data={dataset_desc}; calib batches={len(cal_loader)} eval batches={len(test_loader)} "
               f"of {bs} (this rank's); ranks={1 if pg is None else torch.distributed.get_world_size()}")
 
+    if args.precision == "fp8":
+        # opt-in e4m3 arithmetic for the large projections (BASELINE configs[4]); --fp8-calibrate measures the attention outputs of the
+        # first calibration batches and fixes the e4m3 hand-off scale of every block before anything else runs
+        vp.DEFAULT_PRECISION = "fp8"
+        if args.fp8_calibrate:
+            from ssp2vit.core import _pixels_to_device
+            px = []
+            for b in cal_loader:
+                px.append(_pixels_to_device(b, torch.device(device, torch.cuda.current_device())))
+                if sum(int(t.shape[0]) for t in px) >= 32:
+                    break
+            if hasattr(cal_loader, "epoch"):
+                cal_loader.epoch = 0                                   # the peek must not shift the loader's seeded epoch sequence
+            scales = vp.calibrate_fp8(model, torch.cat(px, 0), device)
+            if rank0:
+                print(f"[FP8] calibrated attention hand-off scales: {scales}")
+    else:
+        vp.DEFAULT_PRECISION = "bf16"
     params_before = vp.count_total_params(model)
     latency_baseline = measure_latency(model, device, img_size=img)
     maxb = args.baseline_eval_batches if args.baseline_eval_batches is not None else args.eval_batches
@@ -198,7 +216,7 @@ def run_one(args, target, run_id):
         "config": {"model": name, "target_sparsity": target, "stage": args.stage, "s1_sparsity": args.s1_sparsity,
                    "s2_sparsity": args.s2_sparsity, "freeze_backbone": False, "replace_classifier": False, "use_adapter": False,
                    "adapter_reduction": None, "eval_batches": args.eval_batches, "min_remaining": args.min_remaining,
-                   "cifar_load": False, "dataset": dataset_desc, "weights": args.weights,
+                   "cifar_load": False, "dataset": dataset_desc, "weights": args.weights, "precision": args.precision,
                    "gpus": 1 if pg is None else torch.distributed.get_world_size()},
         "metrics": {
             "params_before_stage1": params_before, "params_after_stage1": params_s1, "params_after_stage2": params_s2,
@@ -296,6 +314,9 @@ def build_argparser():
     p.add_argument("--synthetic-calib", type=int, default=512)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--score-chain", type=str, default="fp32", choices=["fp32", "bf16_ref"])
+    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp8"],
+                   help="fp8: QKV / out-proj / fc1 / fc2 of launches with >= 4096 token rows on e4m3 MFMA operands (opt-in tolerance mode, configs[4])")
+    p.add_argument("--fp8-calibrate", action="store_true", help="with --precision fp8: measure the attention outputs of the first calibration images and set the e4m3 hand-off scales")
     # accepted and ignored (data / fine-tuning flags of the reference that need the network)
     for flag in ("--load-cifar", "--do-finetune", "--freeze-backbone", "--replace-classifier", "--use-adapter", "--save-adapter",
                  "--use-srp-checkpoint"):

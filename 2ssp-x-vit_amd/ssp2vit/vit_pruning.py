@@ -22,6 +22,7 @@ import torch.nn as nn
 from . import core as _core
 from . import dist as _dist
 from . import weights as _weights
+from ._lib import check as _lib_check
 from .mask_parity import MASK_PARITY_EPS, mask_parity_report
 from .planner import ModelStats, TwoSSPPlan, plan_from_stats
 
@@ -113,11 +114,19 @@ def _fingerprint(model) -> Tuple:
            tuple(type(m).__name__ for m in model.modules())
 
 
-def engine_for(model, device="cuda", max_images: int = 64):
+# Arithmetic of the engines the reference-named functions build: "bf16" (the reference's CPU-autocast arithmetic, the parity mode) or,
+# opt-in, "fp8" (BASELINE configs[4]: QKV / fc1 / fc2 / out-projection of launches with >= 4096 token rows on e4m3 MFMA operands — a
+# tolerance mode).  SSP2_PRECISION sets the default; the CLI's --precision sets this variable.
+DEFAULT_PRECISION = os.environ.get("SSP2_PRECISION", "bf16")
+_FP8_SCALES: Dict[int, List[float]] = {}          # id(model) -> calibrated attention hand-off scales (calibrate_fp8), re-applied when an engine is rebuilt
+
+
+def engine_for(model, device="cuda", max_images: int = 64, precision: Optional[str] = None):
     """Build (or reuse) the HIP engine holding `model`'s current weights.  Raises without a GPU."""
     from .engine import VitEngine
+    precision = precision or DEFAULT_PRECISION
     key = id(model)
-    fp = _fingerprint(model)
+    fp = _fingerprint(model) + (precision,)
     hit = _ENGINES.get(key)
     if hit is not None and hit[0] == fp and hit[1].max_images >= max_images:
         return hit[1]
@@ -125,10 +134,23 @@ def engine_for(model, device="cuda", max_images: int = 64):
         hit[1].close()
     dev = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}") \
         if torch.cuda.is_available() else torch.device(device)
-    eng = VitEngine(_weights.from_module(model), device=dev, max_images=max(int(max_images), 1))
+    eng = VitEngine(_weights.from_module(model), device=dev, max_images=max(int(max_images), 1), precision=precision)
     eng.layout = _weights.detect_layout(model)
+    if precision == "fp8" and key in _FP8_SCALES and len(_FP8_SCALES[key]) == eng.depth:
+        for l, sc in enumerate(_FP8_SCALES[key]):
+            _lib_check(eng.lib.ssp2_fp8_set_attn_scale(eng.h, l, float(sc)))
     _ENGINES[key] = (fp, eng)
     return eng
+
+
+def calibrate_fp8(model, pixel_values: torch.Tensor, device="cuda", headroom: float = 4.0) -> List[float]:
+    """fp8 engines only: measure the attention outputs of `pixel_values` (>= 4096 token rows per launch, e.g. 32 images of 224 x 224) on
+    `model`'s engine and fix each block's e4m3 hand-off scale (VitEngine.calibrate_fp8).  The scales are remembered for this model
+    object and re-applied whenever its engine is rebuilt (a larger workspace, changed weights keep the measured ranges)."""
+    eng = engine_for(model, device, max_images=int(pixel_values.shape[0]), precision="fp8")
+    scales = eng.calibrate_fp8(pixel_values.to(eng.device), headroom)
+    _FP8_SCALES[id(model)] = scales
+    return scales
 
 
 def release_engines() -> None:

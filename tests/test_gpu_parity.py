@@ -577,6 +577,42 @@ def test_cli_on_local_uint8_data_through_the_gpu_input_pipeline(gpu, tmp_path):
                   "--eval-data", str(tmp_path / "eval.npy"), "--output-dir", str(out)])
 
 
+def test_cli_fp8_precision_with_calibration(gpu, tmp_path):
+    """The reference-named API on the opt-in e4m3 path (BASELINE configs[4] through the CLI): `--precision fp8 --fp8-calibrate` builds fp8
+    engines for every call (vit_pruning.DEFAULT_PRECISION), measures the attention outputs of the first calibration images, keeps the
+    scales across engine rebuilds, and the prune completes with the plan's cardinalities; the report says which arithmetic ran.  A
+    bf16 run afterwards is back on bf16 engines (no leakage of the module-level switch)."""
+    import importlib.util
+    import json
+    from conftest import PKG
+    from ssp2vit import vit_pruning as vp
+    spec = importlib.util.spec_from_file_location("auto_2ssp_amd_fp8", os.path.join(PKG, "auto_2ssp.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    seen = []
+    orig = vp.engine_for
+    def spy(*a, **k):
+        e = orig(*a, **k); seen.append((e.precision, [round(float(e.lib.ssp2_fp8_attn_scale(e.h, l)), 6) for l in range(e.depth)])); return e
+    vp.engine_for = spy
+    try:
+        rep = cli.main(["--model", "vit_tiny_patch16_224", "--target", "0.3", "--eval-batches", "2", "--batch-size", "32", "--synthetic-calib", "64",
+                        "--num-classes", "10", "--min-remaining", "256", "--precision", "fp8", "--fp8-calibrate", "--output-dir", str(tmp_path / "f8")])[0]
+        assert rep["config"]["precision"] == "fp8" and seen and all(p == "fp8" for p, _ in seen)
+        scales = seen[0][1]
+        assert all(sc > 0 and float(np.log2(sc)).is_integer() for sc in scales)
+        assert any(sc != 16.0 for sc in scales) and all(sc2 == scales for _, sc2 in seen)       # measured, and re-applied on every rebuild
+        masks = json.load(open(rep["artifacts"]["ffn_prune_masks_path"]))["ffn_masks"]
+        assert len(masks) == 12 and all(sum(r) == rep["plan"]["per_block_neurons_to_prune"] for r in masks)
+        assert len(rep["artifacts"]["pruned_block_indices"]) == rep["plan"]["blocks_to_prune"]
+        seen.clear()
+        rep2 = cli.main(["--model", "vit_tiny_patch16_224", "--target", "0.3", "--eval-batches", "2", "--batch-size", "32", "--synthetic-calib", "64",
+                         "--num-classes", "10", "--min-remaining", "256", "--output-dir", str(tmp_path / "b16")])[0]
+        assert rep2["config"]["precision"] == "bf16" and seen and all(p == "bf16" for p, _ in seen)
+    finally:
+        vp.engine_for = orig
+        vp.DEFAULT_PRECISION = "bf16"
+        vp.release_engines()
+
+
 def test_on_device_compaction_equals_engine_from_sliced_weights(gpu):
     """f2: ssp2_prune_ffn / ssp2_drop_attention on a live engine == a fresh engine built from the host-sliced module
     (reference weight surgery, src/vit_pruning.py:297-311, :499-504): bit-identical logits and scores."""
