@@ -596,10 +596,13 @@ def test_cli_fp8_precision_with_calibration(gpu, tmp_path):
     try:
         rep = cli.main(["--model", "vit_tiny_patch16_224", "--target", "0.3", "--eval-batches", "2", "--batch-size", "32", "--synthetic-calib", "64",
                         "--num-classes", "10", "--min-remaining", "256", "--precision", "fp8", "--fp8-calibrate", "--output-dir", str(tmp_path / "f8")])[0]
-        assert rep["config"]["precision"] == "fp8" and seen and all(p == "fp8" for p, _ in seen)
-        scales = seen[0][1]
+        # (the synthetic loaders label their images with the dense model BEFORE the switch — bf16 engines — and calibrate_fp8 builds the
+        # first fp8 engine with the default scales; from the calibration on every engine is fp8 and carries the measured scales)
+        assert rep["config"]["precision"] == "fp8"
+        first = next(i for i, (p, sc) in enumerate(seen) if p == "fp8" and any(v != 16.0 for v in sc))
+        scales = seen[first][1]
         assert all(sc > 0 and float(np.log2(sc)).is_integer() for sc in scales)
-        assert any(sc != 16.0 for sc in scales) and all(sc2 == scales for _, sc2 in seen)       # measured, and re-applied on every rebuild
+        assert len(seen) > first + 1 and all(p == "fp8" and sc2 == scales for p, sc2 in seen[first:])    # re-applied on every rebuild / reuse
         masks = json.load(open(rep["artifacts"]["ffn_prune_masks_path"]))["ffn_masks"]
         assert len(masks) == 12 and all(sum(r) == rep["plan"]["per_block_neurons_to_prune"] for r in masks)
         assert len(rep["artifacts"]["pruned_block_indices"]) == rep["plan"]["blocks_to_prune"]
