@@ -77,6 +77,7 @@ def run_one(args, target, run_id):
         raise SystemExit("auto_2ssp needs an MI355X: the product path has no CPU fallback")
     pg = _process_group()
     rank0 = pg is None or torch.distributed.get_rank() == 0
+    vp.DEFAULT_PRECISION = "bf16"          # (module-level switch: a previous fp8 run in this process must not leak into this one's set-up)
     if args.weights:
         # a LOCAL checkpoint (reference :636-667 loads its model with from_pretrained / timm.create_model; the network
         # fetches stay out): .safetensors / .pth state dict or an HF save_pretrained directory, any of the three key layouts
