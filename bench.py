@@ -556,13 +556,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # SSP2_REHEARSE_ONE_CARD=1: every rank takes cuda:0 and the ranks meet over gloo (RCCL refuses two ranks on one device).  A
+    # correctness rehearsal of the N-rank job on a one-GPU box — launcher, dealing of the batches, exchange steps, one result line —
+    # whose line says so and is never a scaling figure (the ranks share one card's time).
+    one_card = world > 1 and os.environ.get("SSP2_REHEARSE_ONE_CARD") == "1"
+    if one_card:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1 or ("RANK" in os.environ and os.environ.get("SSP2_FORCE_COLLECTIVES")):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+        if one_card:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
         pg = dist.group.WORLD
 
     from ssp2vit import core, dist as sdist
@@ -611,25 +620,28 @@ def main():
     d_ints = [d_int] * depth
     twins = [eng.pruned_twin([d_int - p.per_block_neurons_to_prune] * depth, max_images=args.batch) for p in plans]
 
-    # ---- synthetic ImageNet-shape inputs, resident in HBM before the timed region; every rank its own shard
-    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    # ---- synthetic ImageNet-shape inputs, resident in HBM before the timed region; every rank its own shard.
+    # Batch b of the GLOBAL calibration / eval set is a function of b alone (seeded per batch), and this rank's k-th batch is global
+    # batch k * world + rank: at a fixed total (--config 2) every world size sees the same images, so the selections must agree.
+    g = torch.Generator(device=dev)
     pp = None
     if args.uint8:
         from ssp2vit.preprocess import GpuPreprocessor
         pp = GpuPreprocessor((img, img), img, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5), device=dev)
 
-    def fresh_pixels():
+    def fresh_pixels(kind, global_batch):
+        g.manual_seed(1 + 2 * global_batch + kind)
         if pp is None:
             return torch.randn(args.batch, 3, img, img, generator=g, device=dev), None
         u8 = torch.randint(0, 256, (args.batch, img, img, 3), generator=g, device=dev, dtype=torch.uint8)
         return pp(u8), u8
 
     calib, evalb = [], []
-    for _ in range(n_cal_b):
-        px, u8 = fresh_pixels()
+    for k in range(n_cal_b):
+        px, u8 = fresh_pixels(0, k * world + rank)
         calib.append({"pixel_values": px, "u8": u8})
-    for _ in range(n_ev_b):
-        px, u8 = fresh_pixels()
+    for k in range(n_ev_b):
+        px, u8 = fresh_pixels(1, k * world + rank)
         x = eng.embed(px); eng.layers(x, args.batch)
         _, pred, _ = eng.head(x, args.batch, want_pred=True)
         evalb.append({"pixel_values": px, "labels": pred.long(), "u8": u8})     # teacher labels: dense model's own argmax
@@ -747,7 +759,7 @@ def main():
         overlap = (time.perf_counter() - t2, o2[3])
         e2.close()
 
-    el = torch.tensor([elapsed, s1_s], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed, s1_s], dtype=torch.float64, device=sdist._default_device(pg) if pg is not None else dev)   # nccl: this card; gloo: host
     if pg is not None:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed, s1_s = float(el[0]), float(el[1])
@@ -782,12 +794,14 @@ def main():
             "pruned_neurons_per_block": plan.per_block_neurons_to_prune,
             "streams": 2 if (args.two_streams or args.overlap_stage1) else 1, "stage1_beside_search": bool(args.overlap_stage1), "search": "layer-major" if args.batch_candidates else "candidate-major",
         }
+        if one_card:
+            line["rehearsal"] = f"{world} ranks share ONE card over gloo (SSP2_REHEARSE_ONE_CARD=1): a correctness rehearsal, not a scaling figure"
         if overlap is not None:
             line["stage1_beside_search"] = {"ms_per_step": round(1e3 * overlap[0] / args.steps, 2), "value": round(units_step * args.steps / overlap[0], 1),
                                             "streams": 2, "same_selection": overlap[1] == out[3],
                                             "note": "stage 1 on a second HIP stream with its own engine workspace beside the layer-major search; secondary figure (bench.py --overlap-stage1 makes it the timed region)"}
         if coll is not None:
-            line["collectives"] = {"backend": "nccl (RCCL)", "world_size": world,
+            line["collectives"] = {"backend": "gloo (one-card rehearsal)" if one_card else "nccl (RCCL)", "world_size": world,
                                    "device_ms_per_step": {k: round(v / args.steps, 3) for k, v in coll.items()}}
         if prof is not None and prof.launches:
             # dominant kernel family: fc1 (+bias +erf-GELU; + fused activation-L2 partials in stage 1).

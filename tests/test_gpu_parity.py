@@ -1896,3 +1896,46 @@ def test_tail_over_all_slots_gives_the_per_slot_tails_integers_and_logits(gpu):
         l1, p1, c1 = eng.tail(x[s_ * rows:(s_ + 1) * rows], n, None, labels=labels, want_logits=True, want_pred=True)
         assert torch.equal(lg[s_ * n:(s_ + 1) * n], l1) and torch.equal(pr[s_ * n:(s_ + 1) * n], p1) and int(cc[s_]) == int(c1[0])
     eng.close()
+
+
+@pytest.mark.timeout(900)
+def test_two_and_three_ranks_sharing_the_card_equal_the_single_rank_result(gpu, tmp_path):
+    """SURVEY §8(e) on hardware, as far as one card allows: P = 2 and P = 3 processes, each with its own VitEngine on cuda:0, are
+    dealt the batches they own (batch b -> rank b % P; ragged last batches; with P = 3 a rank owns ONE eval batch) and run the
+    product's sharded stage 1 (both chains) + one-shot depth search + top-1, exchanging over gloo (RCCL refuses two ranks on one
+    device; the collectives are the same calls, the tensors take `dist.device_for_backend`'s host route).  Every rank's scores,
+    candidate counts and totals are bit-identical to the single-process run — the real engine, not the CPU stand-in of
+    tests/test_dist_cpu.py."""
+    import socket
+    import torch.multiprocessing as mp
+    import two_rank_gpu_worker as W
+    model, batch = "vit_tiny_patch16_224", 24
+    n_cal, n_ev = 4 * batch + 10, 2 * batch + 7
+    g = torch.Generator().manual_seed(21)
+    px = torch.randn(n_cal + n_ev, 3, 224, 224, generator=g)
+    eng = W.make_engine(model, 12 * batch)
+    ev = px[n_cal:].to(gpu)
+    labels = []
+    for s in range(0, n_ev, batch):                                   # teacher labels: the dense model's own argmax, a few flipped
+        part = ev[s:s + batch]
+        x = eng.embed(part); eng.layers(x, part.shape[0])
+        labels.append(eng.head(x, part.shape[0], want_pred=True)[1].long().cpu())
+    labels = torch.cat(labels); labels[::7] = (labels[::7] + 1) % 1000
+    eng.close()
+    data = {"px": px, "labels": labels, "batch": batch, "depth": 12, "d_int": 768, "n_calib": n_cal, "n_eval": n_ev, "model": model, "cap": 12 * batch}
+    ref = W.run(lambda: W.make_engine(model, 12 * batch), data, 0, 1, None, False)
+    assert ref["total"] == n_ev and 0 < ref["base"] < n_ev and len(set(ref["cand"])) > 1
+    path = str(tmp_path / "data.pt")
+    torch.save(data, path)
+    for world in (2, 3):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        out = tmp_path / f"ws{world}"; out.mkdir()
+        mp.spawn(W.worker, args=(world, port, path, str(out)), nprocs=world, join=True)
+        for r in range(world):
+            res = torch.load(str(out / f"r{r}.pt"), weights_only=True)
+            for a, b in zip(res["imps"], ref["imps"]):
+                assert torch.equal(a, b), (world, r)
+            for a, b in zip(res["imps_bf"], ref["imps_bf"]):
+                assert a.dtype == b.dtype and torch.equal(a, b), (world, r)
+            assert (res["base"], res["cand"], res["total"], res["top1"]) == (ref["base"], ref["cand"], ref["total"], ref["top1"]), (world, r)
+            assert res["stats"]["batches_owned"] > 0 and res["stats"]["exchanges"] >= 2
