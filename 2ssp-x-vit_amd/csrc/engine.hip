@@ -119,6 +119,7 @@ struct ssp2_engine {
   uint8_t *hbuf8 = nullptr, *act8 = nullptr;   // LayerNorm output / FFN activation as e4m3 bytes
   float* hscale = nullptr;                     // per-row activation scale of hbuf8 (amax / 448, written by the LayerNorm)
   unsigned int* ln_sync = nullptr;             // fused LayerNorm: queue heads + panel arrival counters (GemmArgs.ln_sync)
+  unsigned int* dg_scratch = nullptr;          // deferred residual: 128 KiB per CU where a workgroup parks a tile (GemmArgs.dg)
   int ln_set = 0;                              // queue-head set of the next fused launch (the launch zeroes the other one)
   int n_xcc_seen = 0;
   bool xcc_ok = false;                         // XCC_ID probe at create: ids 0..7 seen, nothing else (else the fused form stays off)
@@ -210,7 +211,7 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
   g.tiles_m = (g.M + 255) / 256;
   g.tiles_n = (g.N + 255) / 256;
   // tile order: plain N-fastest unless SSP2_OPT_GROUP256 asks for column groups (100 * GM + GN, see gemm256.hip.h set_tile)
-  g.group_m = (EPI == EPI_RESID && SCORE > 0) ? 0 : e->opt[SSP2_OPT_GROUP256];
+  g.group_m = (EPI == EPI_RESID && SCORE >= 3) ? 0 : e->opt[SSP2_OPT_GROUP256];
   if (F8 && (g.K % 128 || !g.wscale)) return fail(SSP2_EINVAL, "fp8 GEMM needs K %% 128 == 0 and per-row weight scales (K=%d)", g.K);
   static bool attr_done[kMaxDevices] = {};
   if (!attr_done[e->dev]) {
@@ -218,8 +219,12 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
     attr_done[e->dev] = true;
   }
   g.nt_out = e->opt[SSP2_OPT_NT_STORES];
-  if (!(EPI == EPI_RESID && SCORE > 0)) g.reverse = next_dir(e);
+  if (!(EPI == EPI_RESID && SCORE >= 3)) g.reverse = next_dir(e);
   else { g.ln_sync = e->ln_sync; g.ln_set = e->ln_set; e->ln_set ^= 1; }      // LayerNorm behind the epilogue: per-XCD tile queues
+  if (EPI == EPI_RESID && SCORE == 1) {
+    if (!e->dg_scratch || g.N % 256 || g.K / 64 < 4) return fail(SSP2_EINVAL, "deferred residual: N %% 256, K >= 256 and the parking area are required");
+    g.dg = e->dg_scratch;
+  }
   ProfScope ps(e, klass, 2.0 * g.M * (double)g.N * g.K);
   const int wgs = std::min(g.tiles_m * g.tiles_n, e->n_cu);
   hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, SCORE, F8>), dim3(wgs), dim3(512), G256::LDS, e->stream, g);
@@ -276,7 +281,12 @@ template <int EPI, int SCORE = 0>
 static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
   if (g.K % GEMM_BK) return fail(SSP2_EINVAL, "GEMM K=%d not a multiple of %d", g.K, GEMM_BK);
   if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID || EPI == EPI_FC1) {
-    if (g.M >= big_tile_min_rows(e) && !(EPI == EPI_FC1 && (g.out2 || !e->opt[SSP2_OPT_FC1_BIG_TILES])) && e->opt[SSP2_OPT_BIG_TILES]) return launch_gemm256<EPI, SCORE>(e, g, klass);
+    if (g.M >= big_tile_min_rows(e) && !(EPI == EPI_FC1 && (g.out2 || !e->opt[SSP2_OPT_FC1_BIG_TILES])) && e->opt[SSP2_OPT_BIG_TILES]) {
+      if constexpr (EPI == EPI_RESID && SCORE == 0) {      // the deferred residual (same bits): full column tiles, a main loop long enough to ride on
+        if (e->opt[SSP2_OPT_DEFER_RESID] && e->dg_scratch && g.N % 256 == 0 && g.K / 64 >= 4) return launch_gemm256<EPI_RESID, 1>(e, g, klass);
+      }
+      return launch_gemm256<EPI, SCORE>(e, g, klass);
+    }
   }
   return launch_gemm_small<EPI, SCORE>(e, g, klass);
 }
@@ -442,6 +452,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
     e->opt[SSP2_OPT_FP8_PROJ] = env_int("SSP2_FP8_PROJ", 1);
     e->opt[SSP2_OPT_BIG_TILE_MIN_ROWS] = std::max(256, env_int("SSP2_BIG_TILE_MIN_ROWS", kBigTileMinRowsDefault));
     e->opt[SSP2_OPT_NT_STORES] = env_int("SSP2_NT_STORES", 1);
+    e->opt[SSP2_OPT_DEFER_RESID] = env_int("SSP2_DEFER_RESID", 0);
   }
   e->d_int.assign(d.d_int, d.d_int + d.depth);
   e->d.d_int = e->d_int.data();
@@ -496,6 +507,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
   TRY(dalloc(e, &e->act_cls, (size_t)d.max_images * e->ld_int_max, true));
   TRY(dalloc(e, &e->logits, (size_t)d.max_images * d.classes, true));
   TRY(dalloc(e, &e->ln_sync, (size_t)16 + (M + 255) / 256 + 1, true));
+  TRY(dalloc(e, &e->dg_scratch, (size_t)std::max(e->n_cu, 1) * 32768, true));      // 128 KiB per workgroup of the persistent GEMM
 #undef TRY
   {   // the fused LayerNorm trusts the hardware's XCC_ID to name the L2 a workgroup sits behind: look at what it reports once
     unsigned int* ids = nullptr;
@@ -1226,6 +1238,15 @@ int ssp2_linear_bf16(void* hip_stream, int epilogue, const uint16_t* a_dev, int 
       return big ? launch_gemm256<EPI_FC1, 0>(&e, g, -2) : launch_gemm_small<EPI_FC1, 0>(&e, g, -2);
     case SSP2_EPI_RESID:
       if (!x_dev || ldx < N || (ldx % 4)) return fail(SSP2_EINVAL, "linear: x / ldx");
+      if (big && N % 256 == 0 && K / 64 >= 4) {     // SSP2_DEFER_RESID=1: the deferred residual, as the forward would take it
+        const char* v = getenv("SSP2_DEFER_RESID");
+        if (v && atoi(v)) {
+          static unsigned int* park[kMaxDevices] = {};
+          if (!park[e.dev] && hipMalloc((void**)&park[e.dev], (size_t)n_cu * 131072) != hipSuccess) return fail(SSP2_ENOMEM, "linear: parking area");
+          e.dg_scratch = park[e.dev];
+          return launch_gemm256<EPI_RESID, 1>(&e, g, -2);
+        }
+      }
       return big ? launch_gemm256<EPI_RESID>(&e, g, -2) : launch_gemm_small<EPI_RESID>(&e, g, -2);
     default: return fail(SSP2_EINVAL, "unknown epilogue %d", epilogue);
   }

@@ -69,6 +69,9 @@ struct GemmArgs {
   // ... scheduling state of that form (see gemm256.hip.h, LNV): [0..15] two sets of 8 per-XCD tile-queue counters (a launch
   // uses set ln_set and zeroes the other one for the next fused launch), [16 + p] arrival counter of row panel p (left at 0)
   unsigned int* ln_sync; int ln_set;
+  // Deferred residual (gemm256 kernel, EPI_RESID with SCORE = 1): per workgroup 256 x 256 bf16 (128 KiB) where a tile's
+  // bf16(acc + bias) is parked until the NEXT tile's main loop adds it to x (see gemm256.hip.h, DG); [gridDim.x][8 waves][16 KiB]
+  unsigned int* dg;
 #ifdef GEMM_STAMPS
   unsigned long long* stamps; // diagnostic build only: [blocks][64] s_memtime values of wave 0
 #endif

@@ -98,7 +98,13 @@ template <int EPI, int SCORE = 0, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   using C = G256;
   constexpr bool SWAP = !(EPI == EPI_FC1 && SCORE != 0);
-  constexpr int LNV = EPI == EPI_RESID ? SCORE : 0;     // > 0: LayerNorm of the finished row panels, N = LNV * 256 (see below)
+  constexpr int LNV = (EPI == EPI_RESID && SCORE >= 3) ? SCORE : 0;     // > 0: LayerNorm of the finished row panels, N = LNV * 256 (see below)
+  // DG (EPI_RESID, SCORE == 1, bf16 operands): the DEFERRED residual.  The epilogue only PARKS the tile — bf16(acc + bias), 128 KiB per
+  // workgroup in g.dg, written row-contiguous through the usual LDS transposition — and the read-add-write of the fp32 x tile
+  // happens during the NEXT tile's main loop, one sixteenth of a wave's 128 x 64 window (16 rows x 32 columns: one 16-byte load of parked
+  // values, two 16-byte loads of x, two stores) per K-tile, in the LOAD phase of the wave — while its SIMD partner feeds the matrix pipe.
+  // x_new = x + float(bf16(acc + bias)) exactly as in the direct form, and every sum over K keeps its order: results are bit-identical.
+  constexpr bool DG = EPI == EPI_RESID && SCORE == 1 && !F8;
   constexpr int ESZ = F8 ? 1 : 2;                       // bytes per operand element
   constexpr int KT = F8 ? 128 : GEMM_BK;                // K elements per K-tile (128 bytes per LDS row either way)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -331,6 +337,135 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       if (g.ln_out8) rows(std::true_type{}); else rows(std::false_type{});
     }
   };
+  // ------------------------------------------------------------------------------------------------ DG: the deferred residual
+  // A STEP s (0..15) of a parked tile is half a block p = s >> 1 = (a, b) of the direct epilogue below: rows a*32 + 8j + dr (j = 2(s & 1),
+  // 2(s & 1) + 1; lane -> dr = lane >> 3), columns b*32 + 4 (lane & 7) .. + 3 of the wave's 128 x 64 window — the parked values as ONE
+  // 16-byte load (lane-linear: the lane that stored them), x as two 16-byte raw-buffer loads (rows past M: out-of-range offsets, loads
+  // return 0 and stores are dropped, as in the direct form).  The three loads of the step that a main-loop slot will finish NEXT are inline
+  // asm with a counted wait of our own (as for the LDS-DMA pieces; hipcc would drain the piece stream in front of a loop-carried load):
+  //   slot of K-tile kt = 1 .. 16 (g0: LOAD(kt,1), g1: LOAD(kt,0)):  wait | 8 adds | 2 stores | 3 loads of the next step
+  //   younger than a slot's loads at the next slot's wait: the 8 pieces of one K-tile -> vmcnt(8) (step 0 goes out at the tile top and is
+  //   retired by K-tile 0's closing wait: the first slot's vmcnt(8) is then already met);
+  //   younger than the pieces a K-tile's closing wait retires: that slot's 5 operations + 4 pieces -> vmcnt(9) instead of vmcnt(4).
+  typedef __attribute__((ext_vector_type(4))) unsigned int dg_u32x4;
+  dg_u32x4 dgd = {0u, 0u, 0u, 0u};
+  f32x4 dgx0 = {0.f, 0.f, 0.f, 0.f}, dgx1 = {0.f, 0.f, 0.f, 0.f};
+  int dg_pm0 = 0, dg_pn0 = 0, dg_prows = 0;      // the parked tile: origin, valid rows of this wave's window (0: nothing parked)
+  int dg_s = 0;                                   // the step whose loads are in flight / in the registers
+  constexpr int DG_STEPS = 16;
+  auto dg_words = [&](const void* ptr) __attribute__((always_inline)) -> i32x4 {      // raw-buffer descriptor: base, stride 0, range 2 GiB
+    const unsigned long long a = (unsigned long long)ptr;
+    i32x4 d;
+    d.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a); d.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    d.z = 0x7ffffff0; d.w = 0x00020000;
+    return d;
+  };
+  struct DgLane { int lane_off, rows_left, l16; };
+  auto dg_lane = [&]() __attribute__((always_inline)) -> DgLane {
+    int le_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(le_));                                      // opaque: recomputed per slot, never parked in registers across the main loop
+    const int dr_ = le_ >> 3, cc_ = le_ & 7;
+    return DgLane{(int)(__umul24((unsigned)dr_, (unsigned)g.ldx) + cc_ * 4) * 4, dg_prows - dr_, le_ * 16};     // ldx < 2^24: one full-rate v_mad_u32_u24
+  };
+  auto dg_row = [&](int s_, int jj) { return (s_ >> 2) * 32 + 8 * (2 * (s_ & 1) + jj); };
+  auto dg_soff = [&](int s_, int jj) { return (dg_row(s_, jj) * g.ldx + ((s_ >> 1) & 1) * 32) * 4; };
+  auto dg_xw = [&](const float* base) { return const_cast<float*>(base) + (size_t)(dg_pm0 + wm * 128) * g.ldx + dg_pn0 + wn * 64; };
+  auto dg_scratch = [&]() { return g.dg + ((size_t)blockIdx.x * 8 + wave) * 4096; };          // this wave's 16 KiB
+  // the three loads of step s_ (steps past the last: every x offset out of range — the counts stay uniform)
+  auto dg_issue = [&](int s_, const DgLane& L) __attribute__((always_inline)) {
+    if constexpr (DG) {
+      const bool live = s_ < DG_STEPS;
+      const int sc = live ? s_ : DG_STEPS - 1;
+      const i32x4 rin = dg_words(dg_xw(g.xin ? g.xin : g.x));
+      const i32x4 rsc = dg_words(dg_scratch());
+      const int v0 = (live && dg_row(sc, 0) < L.rows_left) ? L.lane_off : 0x7fffffff;
+      const int v1 = (live && dg_row(sc, 1) < L.rows_left) ? L.lane_off : 0x7fffffff;
+      const int so0 = __builtin_amdgcn_readfirstlane(dg_soff(sc, 0)), so1 = __builtin_amdgcn_readfirstlane(dg_soff(sc, 1));
+      const int sos = __builtin_amdgcn_readfirstlane(sc * 1024);
+#if defined(DG_ABL) && (DG_ABL & 1)     // ablation (timing only): the slot's arithmetic without its memory operations — three pseudo-loads keep the vmcnt counts
+      asm volatile("s_nop 4\n\tbuffer_load_dword %0, %3, %6, %8 offen\n\tbuffer_load_dword %1, %3, %6, %8 offen\n\tbuffer_load_dword %2, %3, %6, %8 offen"
+                   : "=&v"(dgd.x), "=&v"(dgx0.x), "=&v"(dgx1.x)
+                   : "v"(L.l16), "v"(v0), "v"(v1), "s"(rsc), "s"(rin), "s"(sos), "s"(so0), "s"(so1) : "memory");
+#else
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %3, %6, %8 offen\n\tbuffer_load_dwordx4 %1, %4, %7, %9 offen nt\n\tbuffer_load_dwordx4 %2, %5, %7, %10 offen nt"
+                   : "=&v"(dgd), "=&v"(dgx0), "=&v"(dgx1)
+                   : "v"(L.l16), "v"(v0), "v"(v1), "s"(rsc), "s"(rin), "s"(sos), "s"(so0), "s"(so1) : "memory");
+#endif
+    }
+  };
+  // x += parked for the step in the registers (they have LANDED: the caller's wait), and its two stores
+  auto dg_finish = [&](int s_, dg_u32x4 d_, f32x4 x0_, f32x4 x1_, const DgLane& L) __attribute__((always_inline)) {
+    if constexpr (DG) {
+      const bool live = s_ < DG_STEPS;
+      const int sc = live ? s_ : DG_STEPS - 1;
+      const __amdgpu_buffer_rsrc_t xr_ = __builtin_amdgcn_make_buffer_rsrc(dg_xw(g.x), 0, 0x7ffffff0, 0x00020000);
+      const int v0 = (live && dg_row(sc, 0) < L.rows_left) ? L.lane_off : 0x7fffffff;
+      const int v1 = (live && dg_row(sc, 1) < L.rows_left) ? L.lane_off : 0x7fffffff;
+      {   // eight fp32 adds as four v_pk_add_f32 (IEEE adds, lane by lane: the same sums)
+        f32x2 p0, p1, p2, p3, q0, q1, q2, q3;
+        p0.x = bf16lo_f32(d_.x); p0.y = bf16hi_f32(d_.x); p1.x = bf16lo_f32(d_.y); p1.y = bf16hi_f32(d_.y);
+        p2.x = bf16lo_f32(d_.z); p2.y = bf16hi_f32(d_.z); p3.x = bf16lo_f32(d_.w); p3.y = bf16hi_f32(d_.w);
+        q0.x = x0_.x; q0.y = x0_.y; q1.x = x0_.z; q1.y = x0_.w; q2.x = x1_.x; q2.y = x1_.y; q3.x = x1_.z; q3.y = x1_.w;
+        q0 += p0; q1 += p1; q2 += p2; q3 += p3;
+        x0_.x = q0.x; x0_.y = q0.y; x0_.z = q1.x; x0_.w = q1.y; x1_.x = q2.x; x1_.y = q2.y; x1_.z = q3.x; x1_.w = q3.y;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#if defined(DG_ABL) && (DG_ABL & 2)     // ablation (timing only): two one-dword stores into the parking area instead of the x stores
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(dg_u32x4, x0_).x, __builtin_amdgcn_make_buffer_rsrc(dg_scratch(), 0, 0x7ffffff0, 0x00020000), L.l16, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(dg_u32x4, x1_).x, __builtin_amdgcn_make_buffer_rsrc(dg_scratch(), 0, 0x7ffffff0, 0x00020000), L.l16, 0, 0);
+#else
+#ifndef DG_ST_AUX
+#define DG_ST_AUX 0
+#endif
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dg_u32x4, x0_), xr_, v0, dg_soff(sc, 0), DG_ST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dg_u32x4, x1_), xr_, v1, dg_soff(sc, 1), DG_ST_AUX);
+#endif
+      asm volatile("s_nop 1" ::: "memory");                            // store-data hazard guard, see the direct epilogue
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // a main-loop slot: the step in flight lands, is finished, and the next one goes out
+  auto dg_slot = [&]() __attribute__((always_inline)) {
+    if constexpr (DG) {
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(dgd), "+v"(dgx0), "+v"(dgx1) :: "memory");
+      const DgLane L = dg_lane();
+      dg_finish(dg_s, dgd, dgx0, dgx1, L);
+      ++dg_s;
+      dg_issue(dg_s, L);
+    }
+  };
+  // whatever is left of the parked tile, outside a main loop (a tile's epilogue: steps the main loop had no K-tiles for; after the last
+  // tile: all of it): compiler-visible loads, FOUR steps in flight.  `in_regs`: step dg_s sits in dgd / dgx0 / dgx1 and has landed.
+  auto dg_drain = [&](bool in_regs) __attribute__((always_inline)) {
+    if constexpr (DG) {
+      if (in_regs && dg_s < DG_STEPS) {
+        asm volatile("" : "+v"(dgd), "+v"(dgx0), "+v"(dgx1));
+        dg_finish(dg_s, dgd, dgx0, dgx1, dg_lane());
+        ++dg_s;
+      }
+      const __amdgpu_buffer_rsrc_t rin_ = __builtin_amdgcn_make_buffer_rsrc(dg_xw(g.xin ? g.xin : g.x), 0, 0x7ffffff0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsc_ = __builtin_amdgcn_make_buffer_rsrc(dg_scratch(), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll 1
+      for (; dg_s < DG_STEPS; dg_s += 4) {
+        const DgLane L = dg_lane();
+        dg_u32x4 d_[4]; f32x4 a_[4], b_[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int s_ = dg_s + i;
+          const bool live = s_ < DG_STEPS;
+          const int sc = live ? s_ : DG_STEPS - 1;
+          const int v0 = (live && dg_row(sc, 0) < L.rows_left) ? L.lane_off : 0x7fffffff;
+          const int v1 = (live && dg_row(sc, 1) < L.rows_left) ? L.lane_off : 0x7fffffff;
+          d_[i] = __builtin_bit_cast(dg_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsc_, L.l16, sc * 1024, 0));
+          a_[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin_, v0, dg_soff(sc, 0), 2));
+          b_[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin_, v1, dg_soff(sc, 1), 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dg_finish(dg_s + i, d_[i], a_[i], b_[i], L);
+      }
+    }
+  };
 #ifdef GEMM_STAGGER
   // experiment (timing builds of tools/gemm_bench only): the workgroups of XCD group x = blockIdx.x & 7 start
   // x * (group_m / 100) * 256 cycles late, so that the eight XCDs' epilogue bursts do not meet in HBM (workgroups of one XCD
@@ -367,8 +502,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     // (Round 2 experiment, null result: leaving the epilogue's 16 tail stores in flight here — vmcnt(20) instead of vmcnt(4) —
     // changes nothing within the +-3 % run-to-run spread on any shape: wave 0's 5 k cycles at this barrier are the other
     // waves' epilogues, which run at the HBM write rate when all 256 CUs store together, not its own store drain.)
-    if (counted || (tiles_done == 1 && nk > 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else                                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (DG: the epilogue always ends with the 16 park stores)
+    if (DG || counted || (tiles_done == 1 && nk > 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else                                              asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (LNV > 0) {
       // what wave 4 left in its staging area at the end of the previous tile: [panel to normalise or -1 | queue position claimed
       // for the tile after this one].  That area is the A slot of the previous tile's last K-tile: the ring re-fills it with this
@@ -390,6 +526,10 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     if (F8) asm volatile("v_mov_b32 %0, %0" : "+v"(wsc_lane));
     float asc[4] = {asc_next[0], asc_next[1], asc_next[2], asc_next[3]};     // taken over here for the same reason as the bias
     if (F8) asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(asc[0]), "+v"(asc[1]), "+v"(asc[2]), "+v"(asc[3]));
+    // DG: the three loads of step 0 of the parked tile go out HERE — behind the copy above (hipcc's vmcnt(0) in front of it would wait for
+    // them) and a whole K-tile ahead of their slot: K-tile 0 carries none, its closing wait (everything but its own 4 youngest pieces)
+    // retires them.  On the first tile nothing is parked (dg_prows = 0: every x offset out of range, same counts).
+    if constexpr (DG) dg_issue(0, dg_lane());
     TSTAMP(41);
     // ---- main loop: two wave groups in ping-pong.  A UNIT is half a K-tile: LOAD = 12 fragment reads
     // (ds_read_b128), COMPUTE = 16 MFMAs with 4 LDS-DMA pieces issued BETWEEN the MFMAs (behind pairs 0, 2, 4, 6; s_memtime stamps: a piece
@@ -420,8 +560,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     //   STEADY (compile time): every unit carries its pieces, no conditional anywhere.  Otherwise `flags` decides at run
     //   time (the last two K-tiles of a tile): bit 0 = g0's half-0 unit carries pieces, bit 2 = g1's half-1 unit does,
     //   bit 1 = the other two units do.
-    auto ktile = [&](int kt, int kidx0, int kidx1, auto steady_c, int flags) {
+    auto ktile = [&](int kt, int kidx0, int kidx1, auto steady_c, int flags, auto dg_c) {
       constexpr bool STEADY = decltype(steady_c)::value;
+      constexpr bool DGA = decltype(dg_c)::value;       // DG: this K-tile carries a slot of the deferred residual (steady K-tiles only)
       const bool b_on = STEADY || (flags & 1), a_on = STEADY || (flags & 2), g1h1_on = STEADY || (flags & 4);
       const int sa1 = sa == C::A0 ? C::A1 : (sa == C::A1 ? C::A2 : C::A0);
       const int sa2 = sa1 == C::A0 ? C::A1 : (sa1 == C::A1 ? C::A2 : C::A0);
@@ -476,9 +617,19 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
           for (int i = 0; i < PP_NL; ++i) piece(i);
         }
+        if constexpr (DGA) {
+          // the slot: behind the fragment reads (their LDS latency runs meanwhile), g0 in LOAD(kt,1), g1 in LOAD(kt,0) — in both
+          // groups that is the LOAD phase in FRONT of the unit that carries the A(kt+2) pieces
+          if ((half == 1) != (wm != 0)) {
+            __builtin_amdgcn_sched_barrier(0);
+            dg_slot();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         if (half == 0 && kt < 6) TSTAMP(2 + 6 * kt);
         if (half == 1 && wm) {      // g1: end of phase 4kt+3
-          if (a_on) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+          if constexpr (DGA) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+          else if (a_on) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
           else      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -527,7 +678,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
           }
         if (half == 0 && kt < 6) TSTAMP(5 + 6 * kt);
         if (half == 1 && !wm) {     // g0: end of phase 4kt+3
-          if (a_on) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          if constexpr (DGA) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+          else if (a_on) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
           else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -543,7 +695,11 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     {
       using T_ = std::true_type; using F_ = std::false_type;
       int kt = 0;
-      for (; kt + 2 < nk; ++kt) ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7);
+      if constexpr (DG) {      // K-tile 0: no slot (step 0 is still on its way); K-tiles 1 .. 16: one step each
+        if (kt + 2 < nk) { ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7, F_{}); ++kt; }
+        for (; kt + 2 < nk && kt <= DG_STEPS; ++kt) ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7, T_{});
+      }
+      for (; kt + 2 < nk; ++kt) ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7, F_{});
       if (kt + 1 < nk) {
         // K-tile nk-2: g0's half 0 still carries this tile's B(nk-1); everything "two ahead" is the next tile's K-tile 0
         int k0 = wm ? kt + 2 : kt + 1, k1 = kt + 2, fl = 1;
@@ -556,14 +712,14 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
           ride_base1 = wm ? w_tile : a_tile;
           k0 = wm ? 0 : kt + 1; k1 = 0; fl = 7;
         }
-        ktile(kt, k0, k1, F_{}, fl);
+        ktile(kt, k0, k1, F_{}, fl, F_{});
         ++kt;
       }
       if (kt < nk) {
         // K-tile nk-1: g0 carries B'(0) and A'(1), g1 A'(1); g1's half-1 unit (it would be B'(1), into THIS K-tile's B slot)
         // stays empty — that slot and this K-tile's A slot are the epilogue's staging area; g1 fetches B'(1) at the tile start
         if (has_next) ride_base0 = wm ? a_tile : w_tile;
-        ktile(kt, wm ? 1 : 0, 1, F_{}, has_next ? 3 : 0);
+        ktile(kt, wm ? 1 : 0, 1, F_{}, has_next ? 3 : 0, F_{});
       }
     }
     TSTAMP(60);
@@ -860,6 +1016,46 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       // (Round-1 form: two x blocks in flight per wave through LDS-DMA; every pass then waited ~2.3 k cycles for
       // its block, 20.7 k cycles per tile.)
       constexpr int NXB = 4;
+      if constexpr (DG) {
+        // (1) what the main loop left of the PREVIOUSLY parked tile (K = 768: 10 of its 16 steps ride on K-tiles; K >= 1152: all of them).
+        //     The step in the registers has landed: the closing wait of K-tile nk - 2 retired everything older than its own pieces.
+        dg_drain(true);
+        // (2) park this tile: bf16(acc + bias), row-contiguous through the wave's LDS cells exactly as the direct form reads them,
+        //     16 x 1 KiB lane-linear stores (the lane that stores a 16-byte piece is the lane that will load it)
+        {
+          const int dr = le >> 3, cc = le & 7;
+          char* const cell_lane = stg + l31e * 128;
+          const int csw = (l31e >> 1) & 7;
+          const char* const rd_lane = stg + dr * 128;
+          const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(dg_scratch(), 0, 0x7ffffff0, 0x00020000);
+          const int l16 = le * 16;
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            const int a = p >> 1, b = p & 1;
+            const int buf = (p & 1) * 4096;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v; v.x = pre_f32(a, b, q, 0); v.y = pre_f32(a, b, q, 1); v.z = pre_f32(a, b, q, 2); v.w = pre_f32(a, b, q, 3);
+              lds_st_b128(cell_lane + buf + (((2 * q + lhe) ^ csw) << 4), v);
+            }
+            WAITL0();
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *(const f32x4*)(rd_lane + buf + j * 1024 + ((cc ^ (((8 * j + dr) >> 1) & 7)) << 4));
+            WAITL0();
+            dg_u32x4 w0, w1;
+            w0.x = pack_bf16x2(v[0].x, v[0].y); w0.y = pack_bf16x2(v[0].z, v[0].w); w0.z = pack_bf16x2(v[1].x, v[1].y); w0.w = pack_bf16x2(v[1].z, v[1].w);
+            w1.x = pack_bf16x2(v[2].x, v[2].y); w1.y = pack_bf16x2(v[2].z, v[2].w); w1.z = pack_bf16x2(v[3].x, v[3].y); w1.w = pack_bf16x2(v[3].z, v[3].w);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_raw_buffer_store_b128(w0, rsc, l16, (2 * p) * 1024, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w1, rsc, l16, (2 * p + 1) * 1024, 0);
+            asm volatile("s_nop 1" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // (3) the parked tile is now this one (its step 0 goes out at the top of the next tile, or in the drain behind the last one)
+        dg_pm0 = cur_m0; dg_pn0 = cur_n0; dg_prows = g.M - row0; dg_s = 0;
+      } else
       if (wave_cols_ok) {
         const int dr = le >> 3, cc = le & 7;
         float* const xw = g.x + (size_t)row0 * g.ldx + col0;         // wave's 128 x 64 window of x
@@ -964,6 +1160,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
       lnq_prev_panel = cur_m0 >> 8;
     }
     TSTAMP(40);
+  }
+  if constexpr (DG) {
+    if (tiles_done > 0) dg_drain(false);           // the last tile's residual: nothing rides on anything any more
   }
   if constexpr (LNV > 0) {
     // The queue is empty.  Two panels may still wait for this workgroup: the one its second-to-last tile belongs to (arrival

@@ -1939,3 +1939,39 @@ def test_two_and_three_ranks_sharing_the_card_equal_the_single_rank_result(gpu, 
                 assert a.dtype == b.dtype and torch.equal(a, b), (world, r)
             assert (res["base"], res["cand"], res["total"], res["top1"]) == (ref["base"], ref["cand"], ref["total"], ref["top1"]), (world, r)
             assert res["stats"]["batches_owned"] > 0 and res["stats"]["exchanges"] >= 2
+
+
+@pytest.mark.parametrize("cfg,n_img", [("vit_base_patch16_224_d3", 40), ("vit_large_patch16_224_d2", 40), ("vit_huge_patch14_224_d2", 40),
+                                       # several tiles per workgroup: every tile but a workgroup's first rides on a predecessor, the last one drains alone
+                                       ("vit_base_patch16_224_d3", 640), ("vit_huge_patch14_224_d2", 320)])
+def test_deferred_residual_gives_the_direct_epilogues_bits(gpu, cfg, n_img):
+    """SSP2_OPT_DEFER_RESID (opt-in; csrc/gemm256.hip.h, DG): the residual projections on the persistent 256 x 256 GEMM only PARK
+    bf16(acc + bias) in their epilogue and add it to the fp32 x tile during the NEXT tile's main loop, one sixteenth of a wave's window
+    per K-tile (K = 768: nine of sixteen steps ride, the rest is drained in the epilogue; K >= 1216: all of them).  x + float(bf16(acc +
+    bias)) is the same sum and no K order changes: logits (with and without a skipped attention, i.e. with the residual READ from one
+    stream and written to another in the search), both score sites and a search's counts must be the same bits; a row count that is
+    not a multiple of 256 exercises the out-of-range row offsets of the ragged last panel."""
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights(cfg, classes=10, seed=5, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
+    depth = int(w["depth"])
+    eng = VitEngine(w, max_images=max(n_img, depth * 40))
+    g = torch.Generator().manual_seed(9)
+    px = torch.randn(n_img, 3, 224, 224, generator=g).to(gpu)
+    labels = torch.randint(0, 10, (40,), generator=g)
+    def run():
+        out = [eng.forward_logits(px, attn_skip=sk).cpu() for sk in (None, [0], [depth - 1])]
+        out += [eng.forward_scores(px, site)[0].cpu() for site in ("pre_gelu", "post_gelu")]
+        out.append(core.depth_search_counts(eng, [{"pixel_values": px[:40], "labels": labels}], depth, batch_limit=None))
+        return out
+    assert eng.get_option("defer_resid") == 0                         # opt-in: measured slower than the direct form (DESIGN.md §6)
+    direct = run()
+    eng.set_option("defer_resid", 1)
+    deferred = run()
+    for a, b in zip(direct, deferred):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+        else:
+            assert a == b
+    eng.close()
