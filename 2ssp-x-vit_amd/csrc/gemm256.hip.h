@@ -562,7 +562,9 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     //   bit 1 = the other two units do.
     auto ktile = [&](int kt, int kidx0, int kidx1, auto steady_c, int flags, auto dg_c) {
       constexpr bool STEADY = decltype(steady_c)::value;
-      constexpr bool DGA = decltype(dg_c)::value;       // DG: this K-tile carries a slot of the deferred residual (steady K-tiles only)
+      constexpr int SLOT = decltype(dg_c)::value;       // 0: none; 1 (DG): this K-tile carries a step of the deferred residual (steady K-tiles only)
+      constexpr bool DGA = SLOT == 1;
+      constexpr int SLOT_OPS = SLOT == 1 ? 5 : 0;       // vector-memory operations of the slot: younger than the pieces the closing wait retires
       const bool b_on = STEADY || (flags & 1), a_on = STEADY || (flags & 2), g1h1_on = STEADY || (flags & 4);
       const int sa1 = sa == C::A0 ? C::A1 : (sa == C::A1 ? C::A2 : C::A0);
       const int sa2 = sa1 == C::A0 ? C::A1 : (sa1 == C::A1 ? C::A2 : C::A0);
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
           for (int i = 0; i < PP_NL; ++i) piece(i);
         }
-        if constexpr (DGA) {
+        if constexpr (SLOT != 0) {
           // the slot: behind the fragment reads (their LDS latency runs meanwhile), g0 in LOAD(kt,1), g1 in LOAD(kt,0) — in both
           // groups that is the LOAD phase in FRONT of the unit that carries the A(kt+2) pieces
           if ((half == 1) != (wm != 0)) {
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
         }
         if (half == 0 && kt < 6) TSTAMP(2 + 6 * kt);
         if (half == 1 && wm) {      // g1: end of phase 4kt+3
-          if constexpr (DGA) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+          if constexpr (SLOT != 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 + SLOT_OPS) : "memory");
           else if (a_on) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
           else      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else {
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
           }
         if (half == 0 && kt < 6) TSTAMP(5 + 6 * kt);
         if (half == 1 && !wm) {     // g0: end of phase 4kt+3
-          if constexpr (DGA) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+          if constexpr (SLOT != 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + SLOT_OPS) : "memory");
           else if (a_on) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
           else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -695,11 +697,12 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
     {
       using T_ = std::true_type; using F_ = std::false_type;
       int kt = 0;
+      using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
       if constexpr (DG) {      // K-tile 0: no slot (step 0 is still on its way); K-tiles 1 .. 16: one step each
-        if (kt + 2 < nk) { ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7, F_{}); ++kt; }
-        for (; kt + 2 < nk && kt <= DG_STEPS; ++kt) ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7, T_{});
+        if (kt + 2 < nk) { ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7, S0{}); ++kt; }
+        for (; kt + 2 < nk && kt <= DG_STEPS; ++kt) ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7, S1{});
       }
-      for (; kt + 2 < nk; ++kt) ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7, F_{});
+      for (; kt + 2 < nk; ++kt) ktile(kt, wm ? kt + 2 : kt + 1, kt + 2, T_{}, 7, S0{});
       if (kt + 1 < nk) {
         // K-tile nk-2: g0's half 0 still carries this tile's B(nk-1); everything "two ahead" is the next tile's K-tile 0
         int k0 = wm ? kt + 2 : kt + 1, k1 = kt + 2, fl = 1;
@@ -712,14 +715,14 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
           ride_base1 = wm ? w_tile : a_tile;
           k0 = wm ? 0 : kt + 1; k1 = 0; fl = 7;
         }
-        ktile(kt, k0, k1, F_{}, fl, F_{});
+        ktile(kt, k0, k1, F_{}, fl, S0{});
         ++kt;
       }
       if (kt < nk) {
         // K-tile nk-1: g0 carries B'(0) and A'(1), g1 A'(1); g1's half-1 unit (it would be B'(1), into THIS K-tile's B slot)
         // stays empty — that slot and this K-tile's A slot are the epilogue's staging area; g1 fetches B'(1) at the tile start
         if (has_next) ride_base0 = wm ? a_tile : w_tile;
-        ktile(kt, wm ? 1 : 0, 1, F_{}, has_next ? 3 : 0, F_{});
+        ktile(kt, wm ? 1 : 0, 1, F_{}, has_next ? 3 : 0, S0{});
       }
     }
     TSTAMP(60);
