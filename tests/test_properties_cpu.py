@@ -175,5 +175,75 @@ def test_the_reference_is_really_compared_where_it_exists():
         r = ref_vp()
         assert r is not None and hasattr(r, "plan_2ssp_allocation") and hasattr(r, "prune_vit_mlp_width")
         assert os.path.realpath(r.__file__).startswith(os.path.realpath(REF))
+        assert hasattr(r, "_compute_ffn_activation_importance") and hasattr(r, "evaluate_top1")
     else:
         assert ref_vp() is None
+
+
+_ref_mc = None
+
+
+def ref_mc():
+    """The reference's mask_conjunction module (Auto2SSPInterface), or None where /root/reference does not exist."""
+    global _ref_mc
+    if _ref_mc is None:
+        p = os.path.join(REF, "adaptation-for-Pures-framework")
+        if not os.path.isdir(p):
+            _ref_mc = False
+        else:
+            sys.path.insert(0, p)
+            try:
+                import mask_conjunction as m
+                _ref_mc = m
+            except Exception:
+                _ref_mc = False
+            finally:
+                sys.path.remove(p)
+    return _ref_mc or None
+
+
+ORACLE_CFG = settings(max_examples=25, deadline=None, database=None, derandomize=True)
+
+
+@ORACLE_CFG
+@given(layout=st.sampled_from(["timm", "hf"]), heads=st.sampled_from([1, 2, 4]), head_dim=st.sampled_from([8, 16]), inter=st.integers(8, 80),
+       depth=st.integers(1, 5), sizes=st.lists(st.integers(1, 7), min_size=1, max_size=4), limit=st.one_of(st.none(), st.integers(0, 5)),
+       seed=st.integers(0, 10 ** 6))
+def test_the_oracle_equals_the_reference_on_random_tiny_models(layout, heads, head_dim, inter, depth, sizes, limit, seed):
+    """§8(c): the oracle (oracle/ref_cpu.py — the checker of every GPU parity test) against the reference ITSELF on geometries and
+    loaders the committed fixtures do not hold: both anatomies, 1-5 blocks, ragged batches of 1-7 images, batch limits from 0 (no batch
+    at all) upwards.  Stage-1 scores in the reference's bf16 chain must be the same BITS and dtype, top-1 the same float, the
+    depth-importance vector the same tensor.  Without the reference (every box but the build container) the oracle's own
+    consistency is checked: a limit beyond the loader changes nothing, a limit of 0 gives zeros."""
+    from oracle import ref_cpu
+    torch.set_num_threads(2)
+    m = tiny_model(layout, heads, head_dim, inter, depth, 10, seed % 5)
+    g = torch.Generator().manual_seed(seed)
+    batches = [{"pixel_values": torch.randn(n, 3, 32, 32, generator=g), "labels": torch.randint(0, 10, (n,), generator=g)} for n in sizes]
+    imps = ref_cpu.ffn_activation_importance(m, batches, batch_limit=limit)
+    acc = ref_cpu.evaluate_top1(m, batches, limit)
+    assert len(imps) == depth and all(t.shape == (inter,) for t in imps)
+    if limit == 0:
+        assert all(float(t.abs().sum()) == 0.0 for t in imps) and acc == 0.0
+    if limit is not None and limit >= len(sizes):
+        again = ref_cpu.ffn_activation_importance(m, batches, batch_limit=None)
+        assert all(torch.equal(a, b) for a, b in zip(imps, again))
+    rv, rm = ref_vp(), ref_mc()
+    if rv is not None:
+        want = quiet(rv._compute_ffn_activation_importance, m, batches, device="cpu", batch_limit=limit)
+        for a, b in zip(want, imps):
+            assert a.dtype == b.dtype and torch.equal(a, b)
+        assert quiet(rv.evaluate_top1, m, batches, device="cpu", max_batches=limit) == acc
+    if rm is not None and depth >= 2:
+        iface = rm.Auto2SSPInterface(m, batches, device="cpu", importance_mode="copy", batch_limit=limit if limit is not None else 5)
+        want = quiet(iface._compute_att_depth_importance)
+        got = ref_cpu.att_depth_importance(m, batches, batch_limit=limit if limit is not None else 5)
+        assert want.dtype == got.dtype and torch.equal(want, got)
+
+
+def test_the_reference_interface_is_really_compared_where_it_exists():
+    if os.path.isdir(REF):
+        m = ref_mc()
+        assert m is not None and hasattr(m, "Auto2SSPInterface") and os.path.realpath(m.__file__).startswith(os.path.realpath(REF))
+    else:
+        assert ref_mc() is None
