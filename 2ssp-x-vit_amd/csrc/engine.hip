@@ -405,7 +405,10 @@ static int launch_attn(ssp2_engine* e, int n, RowMap rm, bool cls_only = false, 
   ATTN_CASE(64, 1);
   ATTN_CASE(64, 2);   // 112/16: 50 tokens (test sizes)
   ATTN_CASE(64, 3);
+  ATTN_CASE(64, 4);   // 160/16: 101 tokens
   ATTN_CASE(64, 5);   // 192/16: 145 tokens
+  ATTN_CASE(64, 6);   // 208/16: 170 tokens
+  ATTN_CASE(64, 9);   // 224/14 with d_h = 64: 257 tokens (ViT-L/14)
 #undef ATTN_CASE
   return fail(SSP2_EINVAL, "attention kernel not instantiated for d_h=%d, tokens=%d", e->dh, e->tokens);
 }

@@ -39,6 +39,13 @@ VIT_CONFIGS = {
     "vit_large_patch16_224_d2": (224, 16, 1024, 16, 4096, 2),
     "vit_huge_patch14_224_d2": (224, 14, 1280, 16, 5120, 2),
     "vit_small_patch16_224_d2": (224, 16, 384, 6, 1536, 2),
+    # geometries beside BASELINE's: ViT-L/14 (257 tokens at d_h = 64), ViT-B/32 (50 tokens, 3072-wide patches), B/16 at 160 / 208 pixels
+    "vit_large_patch14_224": (224, 14, 1024, 16, 4096, 24),
+    "vit_base_patch32_224": (224, 32, 768, 12, 3072, 12),
+    "vit_large_patch14_224_d2": (224, 14, 1024, 16, 4096, 2),
+    "vit_base_patch32_224_d2": (224, 32, 768, 12, 3072, 2),
+    "vit_base_patch16_160_d2": (160, 16, 768, 12, 3072, 2),
+    "vit_base_patch16_208_d2": (208, 16, 768, 12, 3072, 2),
 }
 
 

@@ -451,10 +451,15 @@ def test_persistent_attention_is_bit_identical_to_the_one_item_kernel(gpu, cfg, 
 
 
 @pytest.mark.parametrize("cfg,layout", [("vit_huge_patch14_224_d2", "timm"), ("vit_large_patch16_224_d2", "hf"),
-                                        ("vit_small_patch16_224_d2", "timm")])
+                                        ("vit_small_patch16_224_d2", "timm"),
+                                        # beside BASELINE's models: ViT-L/14 (257 tokens at d_h = 64), ViT-B/32 (50 tokens, 3072-wide
+                                        # patches), B/16 at 160 and 208 pixels (101 / 170 tokens: four and six key tiles)
+                                        ("vit_large_patch14_224_d2", "timm"), ("vit_base_patch32_224_d2", "hf"),
+                                        ("vit_base_patch16_160_d2", "timm"), ("vit_base_patch16_208_d2", "hf")])
 def test_other_geometries_vs_oracle(gpu, cfg, layout):
     """Kernel shapes of BASELINE configs 4/5: H/14 (257 tokens, d_h = 80, patch K = 588 padded to 640, d = 1280) and
-    L/16 (d = 1024, 16 heads), plus S/16 (d = 384); two-block cuts so the CPU oracle finishes in seconds."""
+    L/16 (d = 1024, 16 heads), plus S/16 (d = 384) and what else a user of the reference's CLI may bring; two-block cuts so the
+    CPU oracle finishes in seconds."""
     from oracle import ref_cpu
     from oracle.vit_modules import build_from_flat
     from ssp2vit.engine import VitEngine
@@ -462,7 +467,7 @@ def test_other_geometries_vs_oracle(gpu, cfg, layout):
     w = synthetic_weights(cfg, classes=10, seed=8, std=0.03, eps=1e-6 if layout == "timm" else 1e-12, bias_std=0.02)
     model = build_from_flat(w, layout)
     g = torch.Generator().manual_seed(4)
-    px = torch.randn(3, 3, 224, 224, generator=g)
+    px = torch.randn(3, 3, int(w["img"]), int(w["img"]), generator=g)
     eng = VitEngine(w, max_images=3)
     ref = ref_cpu.logits_of(model, px).float()
     got = eng.forward_logits(px.to(gpu)).cpu()
