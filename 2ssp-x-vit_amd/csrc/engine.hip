@@ -408,6 +408,7 @@ static int launch_attn(ssp2_engine* e, int n, RowMap rm, bool cls_only = false, 
   ATTN_CASE(64, 4);   // 160/16: 101 tokens
   ATTN_CASE(64, 5);   // 192/16: 145 tokens
   ATTN_CASE(64, 6);   // 208/16: 170 tokens
+  ATTN_CASE(64, 8);   // 240/16: 226 tokens
   ATTN_CASE(64, 9);   // 224/14 with d_h = 64: 257 tokens (ViT-L/14)
 #undef ATTN_CASE
   return fail(SSP2_EINVAL, "attention kernel not instantiated for d_h=%d, tokens=%d", e->dh, e->tokens);

@@ -46,6 +46,7 @@ VIT_CONFIGS = {
     "vit_base_patch32_224_d2": (224, 32, 768, 12, 3072, 2),
     "vit_base_patch16_160_d2": (160, 16, 768, 12, 3072, 2),
     "vit_base_patch16_208_d2": (208, 16, 768, 12, 3072, 2),
+    "vit_base_patch16_240_d2": (240, 16, 768, 12, 3072, 2),
 }
 
 

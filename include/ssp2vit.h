@@ -60,7 +60,7 @@ typedef struct {
   int32_t patch;        /* patch size; tokens N = (img/patch)^2 + 1                */
   int32_t dim;          /* hidden size, multiple of 64                             */
   int32_t heads;        /* dim/heads in {16, 64, 80}; tokens = (img/patch)^2 + 1 must fall into an instantiated key-tile count:
-                         * d_h 64: up to 96, 97..224 or 257..288 tokens (ViT-Ti/S/B/L at /16 and /32, 160..224 pixels; ViT-L/14); d_h 80: 257..288 (ViT-H/14);
+                         * d_h 64: up to 288 tokens (ViT-Ti/S/B/L at /16 and /32 up to 256 pixels; ViT-L/14); d_h 80: 257..288 (ViT-H/14);
                          * d_h 16: up to 32 — anything else fails at the first forward with SSP2_EINVAL */
   int32_t depth;        /* encoder blocks L                                        */
   int32_t classes;

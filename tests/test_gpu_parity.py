@@ -453,9 +453,10 @@ def test_persistent_attention_is_bit_identical_to_the_one_item_kernel(gpu, cfg, 
 @pytest.mark.parametrize("cfg,layout", [("vit_huge_patch14_224_d2", "timm"), ("vit_large_patch16_224_d2", "hf"),
                                         ("vit_small_patch16_224_d2", "timm"),
                                         # beside BASELINE's models: ViT-L/14 (257 tokens at d_h = 64), ViT-B/32 (50 tokens, 3072-wide
-                                        # patches), B/16 at 160 and 208 pixels (101 / 170 tokens: four and six key tiles)
+                                        # patches), B/16 at 160, 208 and 240 pixels (101 / 170 / 226 tokens: four, six and eight key tiles)
                                         ("vit_large_patch14_224_d2", "timm"), ("vit_base_patch32_224_d2", "hf"),
-                                        ("vit_base_patch16_160_d2", "timm"), ("vit_base_patch16_208_d2", "hf")])
+                                        ("vit_base_patch16_160_d2", "timm"), ("vit_base_patch16_208_d2", "hf"),
+                                        ("vit_base_patch16_240_d2", "timm")])
 def test_other_geometries_vs_oracle(gpu, cfg, layout):
     """Kernel shapes of BASELINE configs 4/5: H/14 (257 tokens, d_h = 80, patch K = 588 padded to 640, d = 1280) and
     L/16 (d = 1024, 16 heads), plus S/16 (d = 384) and what else a user of the reference's CLI may bring; two-block cuts so the
