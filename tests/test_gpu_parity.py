@@ -1981,3 +1981,26 @@ def test_deferred_residual_gives_the_direct_epilogues_bits(gpu, cfg, n_img):
         else:
             assert a == b
     eng.close()
+
+
+@pytest.mark.parametrize("model,depth,d_int", [("vit_base_patch32_224", 12, 3072), ("vit_large_patch14_224", 24, 4096)])
+def test_cli_end_to_end_on_geometries_beside_baselines(gpu, tmp_path, model, depth, d_int):
+    """The whole CLI (plan -> stage 1 -> one-shot search -> apply -> report) on two models a user of the reference's CLI may bring and
+    BASELINE.json does not name: ViT-B/32 (50 tokens: the unfused scoring path, 3072-wide patch rows) and ViT-L/14 (257 tokens at
+    d_h = 64).  Checked: the plan is carried out (mask cardinalities, block count, removed share within 2 points of the target),
+    the dense model scores 1.0 on its own teacher labels, and the pruned engine still evaluates."""
+    import importlib.util
+    import json
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("auto_2ssp_amd", os.path.join(PKG, "auto_2ssp.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    out = tmp_path / "run"
+    rep = cli.main(["--model", model, "--target", "0.3", "--eval-batches", "1", "--batch-size", "16", "--synthetic-calib", "16",
+                    "--num-classes", "10", "--output-dir", str(out)])[0]
+    m, plan = rep["metrics"], rep["plan"]
+    assert plan["num_blocks_total"] == depth and m["acc_baseline"] == 1.0 and 0.0 <= m["acc_stage2"] <= 1.0
+    assert len(rep["artifacts"]["pruned_block_indices"]) == plan["blocks_to_prune"] > 0
+    masks = json.load(open(rep["artifacts"]["ffn_prune_masks_path"]))["ffn_masks"]
+    assert len(masks) == depth and all(len(r) == d_int and sum(r) == plan["per_block_neurons_to_prune"] for r in masks)
+    removed = (m["params_before_stage1"] - m["params_after_stage2"]) / m["params_before_stage1"]
+    assert abs(removed - 0.3) < 0.02, removed
