@@ -396,6 +396,12 @@ static bool attn_persistent(const ssp2_engine* e) {
   const int nt = (e->tokens + 31) / 32;
   return e->opt[SSP2_OPT_ATTN_PERSIST] && ((e->dh == 64 && nt >= 4 && nt <= 7) || (e->dh == 80 && nt == 9 && e->tokens == 257));
 }
+// (head dim, 32-key tiles) pairs launch_attn below has an instantiation for — checked when an engine is created, so that an
+// unsupported geometry fails THERE and not at the first forward
+static bool attn_supported(int dh, int tokens) {
+  const int nt = (tokens + 31) / 32;
+  return (dh == 64 && nt >= 1 && nt <= 9) || (dh == 80 && nt == 9) || (dh == 16 && nt == 1);
+}
 static int launch_attn(ssp2_engine* e, int n, RowMap rm, bool cls_only = false, uint8_t* out8 = nullptr, float out8_scale = ATTN_OUT8_SCALE) {
   const int nt = (e->tokens + 31) / 32;
 #define ATTN_CASE(DH_, NT_) if (e->dh == DH_ && nt == NT_) return cls_only ? launch_attn_t<DH_, NT_, true>(e, n, rm) : launch_attn_t<DH_, NT_, false>(e, n, rm, out8, out8_scale)
@@ -469,6 +475,11 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
   if (!(e->dh == 16 || e->dh == 64 || e->dh == 80)) {
     delete e;
     return fail(SSP2_EINVAL, "head dim %d unsupported (16, 64, 80)", d.dim / d.heads);
+  }
+  if (!attn_supported(e->dh, e->tokens)) {
+    const int dh = e->dh, tk = e->tokens;
+    delete e;
+    return fail(SSP2_EINVAL, "no attention kernel for head dim %d with %d tokens (head dim 64: up to 288 tokens; 80: 257..288; 16: up to 32)", dh, tk);
   }
   int rc = 0;
 #define TRY(x) do { if ((rc = (x))) { ssp2_destroy(e); return rc; } } while (0)

@@ -61,7 +61,7 @@ typedef struct {
   int32_t dim;          /* hidden size, multiple of 64                             */
   int32_t heads;        /* dim/heads in {16, 64, 80}; tokens = (img/patch)^2 + 1 must fall into an instantiated key-tile count:
                          * d_h 64: up to 288 tokens (ViT-Ti/S/B/L at /16 and /32 up to 256 pixels; ViT-L/14); d_h 80: 257..288 (ViT-H/14);
-                         * d_h 16: up to 32 — anything else fails at the first forward with SSP2_EINVAL */
+                         * d_h 16: up to 32 — anything else is refused by ssp2_create with SSP2_EINVAL */
   int32_t depth;        /* encoder blocks L                                        */
   int32_t classes;
   float   ln_eps;       /* 1e-6 timm, 1e-12 HF                                     */

@@ -2004,3 +2004,23 @@ def test_cli_end_to_end_on_geometries_beside_baselines(gpu, tmp_path, model, dep
     assert len(masks) == depth and all(len(r) == d_int and sum(r) == plan["per_block_neurons_to_prune"] for r in masks)
     removed = (m["params_before_stage1"] - m["params_after_stage2"]) / m["params_before_stage1"]
     assert abs(removed - 0.3) < 0.02, removed
+
+
+def test_unsupported_geometries_fail_when_the_engine_is_created(gpu):
+    """Fail loudly and EARLY: a head dimension or a token count no attention kernel is instantiated for is refused by ssp2_create with a
+    message that names the supported set — not at the first forward, and never by a silent fallback."""
+    from ssp2vit._lib import Ssp2Error
+    from ssp2vit.engine import VitEngine
+    from ssp2vit import weights as W
+    W.VIT_CONFIGS["_t_b16_384"] = (384, 16, 768, 12, 3072, 1)      # 577 tokens at d_h = 64: K + V of a head do not fit the LDS
+    W.VIT_CONFIGS["_t_dh32"] = (224, 16, 384, 12, 1536, 1)         # d_h = 32
+    W.VIT_CONFIGS["_t_h14_196"] = (196, 14, 1280, 16, 5120, 1)     # d_h = 80 with 197 tokens
+    try:
+        for name, frag in (("_t_b16_384", "577 tokens"), ("_t_dh32", "head dim 32"), ("_t_h14_196", "197 tokens")):
+            w = W.synthetic_weights(name, classes=10, seed=0)
+            with pytest.raises(Ssp2Error) as ei:
+                VitEngine(w, max_images=2)
+            assert frag in str(ei.value), str(ei.value)
+    finally:
+        for k in ("_t_b16_384", "_t_dh32", "_t_h14_196"):
+            W.VIT_CONFIGS.pop(k, None)
