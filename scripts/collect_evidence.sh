@@ -4,7 +4,7 @@
 #   bash scripts/collect_evidence.sh r04_zz
 TAG=${1:?tag}
 cd "$(dirname "$0")/.."
-for f in bench.jsonl bench_kernel_stats.csv bench_variants.jsonl bench_config2_n1.jsonl other_models.jsonl pytest_gpu.log trace_gaps.json; do
+for f in bench.jsonl bench_kernel_stats.csv bench_variants.jsonl bench_config2_n1.jsonl other_models.jsonl pytest_gpu.log trace_gaps.json h14_bf16_kernel_stats.csv h14_fp8_kernel_stats.csv; do
   [ -f gpurun_out/${TAG}_$f ] && cp gpurun_out/${TAG}_$f profiles/${TAG}_$f
 done
 cp gpurun_out/${TAG}_pmc_*.json profiles/ 2>/dev/null

@@ -26,3 +26,8 @@ for v in "--host-inputs" "--uint8" "--host-inputs --uint8" "--two-streams"; do
 done
 timeout -k 10 400 python3 bench.py --config 2 --no-cpu-baseline --no-roofline --steps 2 > $O/${TAG}_bench_config2_n1.jsonl 2>> $O/${TAG}_bench_variants.err; echo "config2 rc=$?"
 bash scripts/other_models.sh ${TAG}
+# rocprofv3 kernel stats of the configs[4] shard too (ViT-H/14, bf16 and fp8): the per-kernel averages behind the H/14 claims
+for prec in bf16 fp8; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_h14_${prec} -- python3 bench.py --model vit_huge_patch14_224 --target 0.5 --precision ${prec} --steps 1 --warmup 1 --no-cpu-baseline --no-api --no-overlap-figure --no-sustained > $O/${TAG}_bench_prof_h14_${prec}.log 2>&1
+  cp $(ls -t $O/prof_${TAG}_h14_${prec}/*/*_kernel_stats.csv | head -1) $O/${TAG}_h14_${prec}_kernel_stats.csv; echo "h14 ${prec} kernel stats rc=$?"
+done
