@@ -1,0 +1,36 @@
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo/2ssp-x-vit_amd"); sys.path.insert(0, "/root/repo")
+from ssp2vit import vit_pruning as vp, engine as E
+from ssp2vit.mask_conjunction import Auto2SSPInterface
+from ssp2vit.modules import EngineViT
+from ssp2vit.weights import synthetic_weights
+from ssp2vit.planner import plan_from_stats, stats_from_shapes
+dev = torch.device("cuda:0")
+w = synthetic_weights("vit_base_patch16_224", classes=1000, seed=0, std=0.02, eps=1e-6, spread=4.0)
+plan = plan_from_stats(stats_from_shapes(768, 12, 3072, 1000, 197, 16), 0.375, min_remaining=512)
+g = torch.Generator(device=dev).manual_seed(1)
+calib = [{"pixel_values": torch.randn(64, 3, 224, 224, generator=g, device=dev)} for _ in range(8)]
+evalb = [{"pixel_values": torch.randn(64, 3, 224, 224, generator=g, device=dev), "labels": torch.randint(0, 1000, (64,), generator=g, device=dev)} for _ in range(5)]
+T = {}
+orig_init = E.VitEngine.__init__
+def timed_init(self, *a, **k):
+    torch.cuda.synchronize(); t = time.perf_counter(); orig_init(self, *a, **k); torch.cuda.synchronize()
+    T.setdefault("engine_init", []).append(time.perf_counter() - t)
+E.VitEngine.__init__ = timed_init
+def lap(name, t0):
+    torch.cuda.synchronize(); T.setdefault(name, []).append(time.perf_counter() - t0); return time.perf_counter()
+for it in range(4):
+    model = EngineViT(w).to(dev); torch.cuda.synchronize()
+    T_it0 = t = time.perf_counter()
+    s2 = Auto2SSPInterface(model, evalb, device=dev, importance_mode="copy", batch_limit=len(evalb), min_remaining=512)
+    s1 = Auto2SSPInterface(model, calib, device=dev, batch_limit=None, min_remaining=512)
+    t = lap("ifaces", t)
+    att_fin = s2._att_importance_deferred(); t = lap("att_enqueue(+engine)", t)
+    mlp_fin = s1._mlp_importance_deferred(); t = lap("mlp_enqueue", t)
+    att, mlp = att_fin(), mlp_fin(); t = lap("await", t)
+    res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[plan.per_block_neurons_to_prune] * 12, min_remaining=512, strategy="l1", collect_masks=True, precomputed_importance=[x.to(torch.float32) for x in mlp]); t = lap("width", t)
+    out = vp.prune_vit_attention_blocks(res["model"], sparsity=5 / 12, dataloader=None, device=dev, num_to_prune=5, show_progress=False, selected_indices=[int(i) for i in torch.argsort(att)[:5]]); t = lap("depth", t)
+    T.setdefault("total", []).append(time.perf_counter() - T_it0)
+    vp.release_engines(); del model, res, out
+for k, v in T.items():
+    print(f"{k:24s}", " ".join(f"{x*1e3:7.2f}" for x in v), "ms")
