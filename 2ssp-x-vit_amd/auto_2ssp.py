@@ -115,13 +115,10 @@ def run_one(args, target, run_id):
         vp.DEFAULT_PRECISION = "fp8"
         if args.fp8_calibrate:
             from ssp2vit.core import _pixels_to_device
-            px = []
-            for b in cal_loader:
-                px.append(_pixels_to_device(b, torch.device(device, torch.cuda.current_device())))
-                if sum(int(t.shape[0]) for t in px) >= 32:
-                    break
-            if hasattr(cal_loader, "epoch"):
-                cal_loader.epoch = 0                                   # the peek must not shift the loader's seeded epoch sequence
+            # EVERY rank measures the same images — global batch 0 of the calibration order, whoever owns it — so that all ranks set
+            # the same e4m3 scales and a batch's scores do not depend on the rank that ran it; the peek leaves the loader's epoch alone
+            peek = cal_loader.peek_global(1) if hasattr(cal_loader, "peek_global") else list(cal_loader)[:1]
+            px = [_pixels_to_device(b, torch.device(device, torch.cuda.current_device())) for b in peek]
             scales = vp.calibrate_fp8(model, torch.cat(px, 0), device)
             if rank0:
                 print(f"[FP8] calibrated attention hand-off scales: {scales}")
@@ -144,8 +141,13 @@ def run_one(args, target, run_id):
     imp_mode = "heuristic" if args.stage == "s1" else args.depth_importance
     iface = Auto2SSPInterface(model, cal_loader, device=device, importance_mode=imp_mode, batch_limit=args.eval_batches,
                               min_remaining=args.min_remaining, score_chain=args.score_chain, process_group=pg)
-    mlp_imp = iface._compute_mlp_importance() if (args.stage in ("both", "s1") and args.s1_importance == "act") else None
-    att_imp = iface._compute_att_depth_importance() if args.stage in ("both", "s2") else None
+    if args.stage == "both" and args.s1_importance == "act" and not args.two_pass:
+        # the reference calls the two private methods one after the other (:774-775), each walking cal_loader[:eval_batches] with its own
+        # dense forward; fit() takes both from ONE walk whose dense forward serves the hook and the search's baseline alike
+        att_imp, mlp_imp = iface.fit()
+    else:
+        mlp_imp = iface._compute_mlp_importance() if (args.stage in ("both", "s1") and args.s1_importance == "act") else None
+        att_imp = iface._compute_att_depth_importance() if args.stage in ("both", "s2") else None
 
     ffn_masks = mask_parity = None
     if args.stage in ("both", "s1"):
@@ -317,6 +319,8 @@ def build_argparser():
     p.add_argument("--score-chain", type=str, default="fp32", choices=["fp32", "bf16_ref"])
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp8"],
                    help="fp8: QKV / out-proj / fc1 / fc2 of launches with >= 4096 token rows on e4m3 MFMA operands (opt-in tolerance mode, configs[4])")
+    p.add_argument("--two-pass", action="store_true", help="compute the two importances in two separate walks over the calibration loader, as the reference "
+                                                           "does (default: one walk whose dense forward serves both; a reshuffling loader then feeds both stages the same order)")
     p.add_argument("--fp8-calibrate", action="store_true", help="with --precision fp8: measure the attention outputs of the first calibration images and set the e4m3 hand-off scales")
     # accepted and ignored (data / fine-tuning flags of the reference that need the network)
     for flag in ("--load-cifar", "--do-finetune", "--freeze-backbone", "--replace-classifier", "--use-adapter", "--save-adapter",

@@ -96,6 +96,7 @@ struct ssp2_engine {
   int n_cu = 256;
   int dev = 0;             // HIP device the engine was created on
   int zig = 0;             // direction of the next large launch (next_dir)
+  int zig_hold = -1;       // >= 0: the launches of a split operation all take this direction (next_dir does not advance)
   // Run-time switches (ssp2_set_option).  Their defaults are read from the environment ONCE, in ssp2_create (round 2 called
   // getenv on every launch); tests and A/B scripts flip them per handle.
   int opt[SSP2_OPT_COUNT] = {};
@@ -187,6 +188,7 @@ static int mat_alloc(ssp2_engine* e, Mat& m, int rows, int cols) {
 // (profiles/r02_f_zigzag_ab.txt); SSP2_ZIGZAG=0 switches it off.
 static int next_dir(ssp2_engine* e) {
   if (!e->opt[SSP2_OPT_ZIGZAG]) return 0;
+  if (e->zig_hold >= 0) return e->zig_hold;
   const int d = e->zig; e->zig ^= 1; return d;
 }
 
@@ -838,8 +840,19 @@ int ssp2_layers(ssp2_handle e, float* x, int n, int l_begin, int l_end, const ui
 
 int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_begin, int l_end, const uint8_t* attn_skip, int score_site,
                      int score_chain, int score_group, float* batch_scores, int score_ld) {
+  return ssp2_layers_prefix(e, x_in, x, n, l_begin, l_end, attn_skip, score_site, score_chain, score_group, n, batch_scores, score_ld);
+}
+
+// score_images < n: only the LEADING score_images images of the launch are hooked (whole slabs of the slab layout).  This is the depth
+// search's baseline doubling as the stage-1 pass (reference: ONE loader and ONE batch_limit feed both stages,
+// adaptation-for-Pures-framework/mask_conjunction.py:276-281, :327): slot 0 of the layer-major launch is scored, the candidates' slots
+// behind it are not.  Only the fc1 GEMM is split in two launches at the (256-row aligned) slab boundary; a row's arithmetic does not
+// depend on the launch it is part of, so the stream and the scores are the bits of a scored launch of score_images images alone.
+int ssp2_layers_prefix(ssp2_handle e, const float* x_in, float* x, int n, int l_begin, int l_end, const uint8_t* attn_skip, int score_site,
+                       int score_chain, int score_group, int score_images, float* batch_scores, int score_ld) {
   int rc;
   if ((rc = check_n(e, n, score_group))) return rc;
+  if (score_images <= 0 || score_images > n) return fail(SSP2_EINVAL, "score_images=%d outside (0, n=%d]", score_images, n);
   if (!x) return fail(SSP2_EINVAL, "null x");
   if (l_begin < 0 || l_end > e->d.depth || l_begin > l_end) return fail(SSP2_EINVAL, "bad layer range [%d,%d)", l_begin, l_end);
   const bool scores_only = (score_site & SSP2_SCORE_ONLY) != 0;
@@ -849,8 +862,13 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
   if (score_site && (!batch_scores || score_ld < e->ld_int_max)) return fail(SSP2_EINVAL, "batch_scores needs ld >= %d", e->ld_int_max);
   const RowMap rm = make_rowmap(e->tokens, n, score_group);
   const int D = e->d.dim, M = (int)total_rows(rm, n);
+  const bool prefix = score_site && score_images < n;
+  if (prefix && (rm.group <= 0 || score_images % rm.group != 0 || scores_only))
+    return fail(SSP2_EINVAL, "score_images=%d < n=%d needs the slab layout, whole slabs (group %d) and no SSP2_SCORE_ONLY", score_images, n, score_group);
+  const int ns = score_site ? score_images : n;                                   // images that are hooked
+  const int M0 = prefix ? (score_images / rm.group) * rm.mpad : M;                 // rows of the scored prefix: whole padded slabs
   const int grp = (score_group <= 0 || score_group > n) ? n : score_group;
-  const int n_groups = (n + grp - 1) / grp;
+  const int n_groups = (ns + grp - 1) / grp;
   const size_t group_stride = (size_t)e->d.depth * score_ld;
   const bool fused = score_site && e->tokens >= GEMM_BM;   // a 128-row tile then spans at most two samples
   // fp8 mode: the three large projections of a launch with >= 4096 rows run on e4m3 operands (LayerNorm and the fc1
@@ -926,34 +944,57 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
     h_ready = false;
     const bool f8_mlp = f.wscale != nullptr;
     f.score_site = fused ? score_site : 0; f.tokens = e->tokens; f.slab = e->slab; f.slab_ld = L.ld_int;
-    f.group = rm.group; f.mpad = rm.mpad; f.n_img = n;
+    f.group = rm.group; f.mpad = rm.mpad; f.n_img = ns;
     f.group_m = 8;   // 8 x 8 tile patches per XCD: the 4.7 MB fc1 weight no longer thrashes the 4 MiB L2 (PMC: FETCH_SIZE / 3.7)
     // unfused pre-GELU scoring (models with < 128 tokens): the hook sees fc1's output, fc2 consumes the GELU
     // of it, so the epilogue also stores the pre-activation for the standalone L2 kernel to read.
     f.out2 = (score_site == SSP2_SCORE_PRE_GELU && !fused) ? e->prebuf : nullptr;
-    if (f8_mlp) {
-      if (f.score_site == 1) rc = launch_gemm256<EPI_FC1, 1, true>(e, f, SSP2_K_GEMM_FC1);
-      else if (f.score_site == 2) rc = launch_gemm256<EPI_FC1, 2, true>(e, f, SSP2_K_GEMM_FC1);
-      else rc = launch_gemm256<EPI_FC1, 0, true>(e, f, SSP2_K_GEMM_FC1);
+    auto run_fc1 = [&](GemmArgs& a) -> int {
+      if (f8_mlp) {
+        if (a.score_site == 1) return launch_gemm256<EPI_FC1, 1, true>(e, a, SSP2_K_GEMM_FC1);
+        if (a.score_site == 2) return launch_gemm256<EPI_FC1, 2, true>(e, a, SSP2_K_GEMM_FC1);
+        return launch_gemm256<EPI_FC1, 0, true>(e, a, SSP2_K_GEMM_FC1);
+      }
+      if (a.score_site == 1) return launch_gemm<EPI_FC1, 1>(e, a, SSP2_K_GEMM_FC1);
+      if (a.score_site == 2) return launch_gemm<EPI_FC1, 2>(e, a, SSP2_K_GEMM_FC1);
+      return launch_gemm<EPI_FC1, 0>(e, a, SSP2_K_GEMM_FC1);
+    };
+    if (prefix && fused) {
+      // the hooked slabs with the scoring epilogue, the rest of the launch (the search's candidates) without it
+      // (one operation as far as the zigzag goes: both launches walk in the direction the whole launch would have taken, the part
+      // that direction meets first goes first)
+      GemmArgs r = f;
+      f.M = M0;
+      const int dir = next_dir(e);
+      e->zig_hold = dir;
+      if (!dir && (rc = run_fc1(f))) { e->zig_hold = -1; return rc; }
+      r.M = M - M0; r.score_site = 0; r.n_img = n - ns;
+      if (f8_mlp) {
+        r.A = (const bf16*)((const uint8_t*)r.A + (size_t)M0 * r.lda); r.ascale = r.ascale ? r.ascale + M0 : nullptr;
+        r.out = (bf16*)((uint8_t*)r.out + (size_t)M0 * r.ldo);
+      } else {
+        r.A = r.A + (size_t)M0 * r.lda; r.out = r.out + (size_t)M0 * r.ldo;
+      }
+      rc = run_fc1(r);
+      if (!rc && dir) rc = run_fc1(f);
+      e->zig_hold = -1;
     } else {
-      if (f.score_site == 1) rc = launch_gemm<EPI_FC1, 1>(e, f, SSP2_K_GEMM_FC1);
-      else if (f.score_site == 2) rc = launch_gemm<EPI_FC1, 2>(e, f, SSP2_K_GEMM_FC1);
-      else rc = launch_gemm<EPI_FC1, 0>(e, f, SSP2_K_GEMM_FC1);
+      rc = run_fc1(f);
     }
     if (rc) return rc;
     if (score_site) {
       float* row = batch_scores + (size_t)l * score_ld;
       if (fused) {
         ProfScope ps(e, SSP2_K_SCORE_FINISH);
-        hipLaunchKernelGGL(score_norms_from_slab_kernel, dim3((L.ld_int + 255) / 256, n), dim3(256), 0, e->stream,
-                           e->slab, e->norms, n, rm, L.ld_int, score_chain);
+        hipLaunchKernelGGL(score_norms_from_slab_kernel, dim3((L.ld_int + 255) / 256, ns), dim3(256), 0, e->stream,
+                           e->slab, e->norms, ns, rm, L.ld_int, score_chain);
         hipLaunchKernelGGL(score_colsum_kernel, dim3((L.ld_int + 255) / 256, n_groups), dim3(256), 0, e->stream, e->norms, row,
-                           group_stride, n, grp, L.ld_int, score_chain);
+                           group_stride, ns, grp, L.ld_int, score_chain);
         HIPCHK(hipGetLastError());
       } else {
         const bf16* seen = (score_site == SSP2_SCORE_PRE_GELU) ? e->prebuf : e->actbuf;
         ProfScope ps(e, SSP2_K_ACT_L2);
-        if ((rc = act_l2_impl(e->stream, seen, 0, n, rm, L.d_int, L.ld_int, score_chain, grp, e->norms, row, group_stride))) return rc;
+        if ((rc = act_l2_impl(e->stream, seen, 0, ns, rm, L.d_int, L.ld_int, score_chain, grp, e->norms, row, group_stride))) return rc;
       }
     }
     if (scores_only && l + 1 == l_end) break;            // nothing reads x behind the last hooked activation
@@ -1022,17 +1063,33 @@ int ssp2_tail(ssp2_handle e, const float* x, int n, int attn_skip_last, float* l
 // how many rows a launch has), so the counts are the same integers.  labels [n_slot] is shared by the slots, correct [slots].
 int ssp2_tail_slots(ssp2_handle e, const float* x, int n_slot, int slots, int attn_skip_last, float* logits_dev, int32_t* pred,
                     const int64_t* labels, int64_t* correct) {
+  return ssp2_tail_group(e, x, n_slot, slots, 0, attn_skip_last, logits_dev, pred, labels, correct);
+}
+
+// ... and with the streams in the SLAB layout (group > 0: slabs of `group` images, ssp2_rows; n_slot a multiple of group, so that slot s
+// starts at slab s * n_slot / group): the tail of the search whose baseline doubles as the stage-1 pass (ssp2_layers_prefix).  Pad rows
+// between the slabs take part in the row-wise kernels (LayerNorm, the key / value projection) and are read by nobody.
+int ssp2_tail_group(ssp2_handle e, const float* x, int n_slot, int slots, int group, int attn_skip_last, float* logits_dev, int32_t* pred,
+                    const int64_t* labels, int64_t* correct) {
   int rc;
   if (slots <= 0 || n_slot <= 0) return fail(SSP2_EINVAL, "tail: n_slot=%d slots=%d", n_slot, slots);
   const int n = n_slot * slots;
   const int period = slots > 1 ? n_slot : 0;
-  if ((rc = check_n(e, n))) return rc;
+  if ((rc = check_n(e, n, group))) return rc;
   if (!x) return fail(SSP2_EINVAL, "null x");
-  const int D = e->d.dim, M = n * e->tokens, l = e->d.depth - 1;
+  const RowMap rm = make_rowmap(e->tokens, n, group);
+  if (rm.group > 0 && slots > 1 && n_slot % rm.group != 0) return fail(SSP2_EINVAL, "tail: slots of %d images are not whole slabs of %d", n_slot, group);
+  const int D = e->d.dim, M = (int)total_rows(rm, n), l = e->d.depth - 1;
   Layer& L = e->layers[l];
   if (!(L.ln_set[2] && L.ln_set[3] && L.fc1.w_set && L.fc1.b_set && L.fc2.w_set && L.fc2.b_set)) return fail(SSP2_ESTATE, "last layer MLP weights not loaded");
   // x_cls <- CLS rows of x (x itself is left untouched)
-  HIPCHK(hipMemcpy2DAsync(e->x_cls, (size_t)D * 4, x, (size_t)e->tokens * D * 4, (size_t)D * 4, n, hipMemcpyDeviceToDevice, e->stream));
+  if (rm.group > 0) {
+    ProfScope ps(e, SSP2_K_OTHER);
+    hipLaunchKernelGGL(gather_cls_rows_kernel, dim3((unsigned)(((long)n * (D / 4) + 255) / 256)), dim3(256), 0, e->stream, x, e->x_cls, n, rm, D);
+    HIPCHK(hipGetLastError());
+  } else {
+    HIPCHK(hipMemcpy2DAsync(e->x_cls, (size_t)D * 4, x, (size_t)e->tokens * D * 4, (size_t)D * 4, n, hipMemcpyDeviceToDevice, e->stream));
+  }
   if (!attn_skip_last && !L.attn_dropped) {
     if (!(L.ln_set[0] && L.ln_set[1] && L.qkv.w_set && L.qkv.b_set && L.proj.w_set && L.proj.b_set)) return fail(SSP2_ESTATE, "last layer attention weights not loaded");
     // keys / values need every token; the query, the out-projection and the MLP only the CLS row
@@ -1041,12 +1098,12 @@ int ssp2_tail_slots(ssp2_handle e, const float* x, int n_slot, int slots, int at
     kv.A = e->hbuf; kv.lda = D; kv.W = L.qkv.w + (size_t)D * L.qkv.ld; kv.ldw = L.qkv.ld; kv.bias = L.qkv.b + D;
     kv.M = M; kv.N = 2 * D; kv.K = D; kv.tiles_n = (2 * D + GEMM_BN - 1) / GEMM_BN; kv.out = e->qkvbuf + D; kv.ldo = 3 * D;
     if ((rc = launch_gemm<EPI_BF16>(e, kv, SSP2_K_GEMM_QKV))) return rc;
-    if ((rc = launch_ln(e, x, (size_t)e->tokens * D, L.ln1_g, L.ln1_b, e->h_cls, D, n, D))) return rc;
+    if ((rc = launch_ln(e, x, (size_t)e->tokens * D, L.ln1_g, L.ln1_b, e->h_cls, D, n, D, rm.group > 0 ? rm : RowMap{0, 0, 0}))) return rc;
     GemmArgs q{};
     q.A = e->h_cls; q.lda = D; q.W = L.qkv.w; q.ldw = L.qkv.ld; q.bias = L.qkv.b;
     q.M = n; q.N = D; q.K = D; q.tiles_n = (D + GEMM_BN - 1) / GEMM_BN; q.out = e->q_cls; q.ldo = D;
     if ((rc = launch_gemm<EPI_BF16>(e, q, SSP2_K_GEMM_QKV))) return rc;
-    if ((rc = launch_attn(e, n, RowMap{e->tokens, 0, 0}, true))) return rc;
+    if ((rc = launch_attn(e, n, rm, true))) return rc;
     GemmArgs p{};
     p.A = e->o_cls; p.lda = D; p.W = L.proj.w; p.ldw = L.proj.ld; p.bias = L.proj.b;
     p.M = n; p.N = D; p.K = D; p.tiles_n = L.proj.rows_pad / GEMM_BN; p.x = e->x_cls; p.ldx = D;

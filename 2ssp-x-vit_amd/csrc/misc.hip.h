@@ -51,6 +51,16 @@ __global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ 
   }
 }
 
+// CLS rows of a residual stream in the slab layout -> compact [n, dim] fp32 (the tail of the search; the contiguous layout uses a 2-D copy)
+__global__ void gather_cls_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int n, RowMap rm, int dim) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = dim / 4;
+  if (i < (long)n * q) {
+    const int im = (int)(i / q), c = (int)(i - (long)im * q);
+    ((f32x4*)out)[i] = ((const f32x4*)(x + (size_t)row_of(rm, im) * dim))[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: fp32 rows -> bf16 rows.  One wave per row, the row lives in registers
 // (two-pass mean / variance in fp32), 16-byte loads and 8-byte stores (lane owns float4 chunks lane, lane+64, ..).

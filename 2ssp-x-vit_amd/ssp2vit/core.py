@@ -14,6 +14,32 @@ from . import dist as _dist
 from .mask_parity import mask_parity_report
 
 
+class _OwnedBatches:
+    """Walks a dataloader and yields (global batch index, batch) for the batches THIS rank owns, up to a GLOBAL batch limit
+    (the reference's `batch_limit` / `max_batches`, src/vit_pruning.py:174-176, :347-349, counts batches of the one loader).
+    Plain loader: every rank walks all batches and keeps batch i iff i % P == rank.  `sharded` loader (yields only this rank's batches,
+    its k-th is global batch k * P + rank): the limit applies to the GLOBAL index, so N ranks together cover `limit` batches, not
+    N x limit.  `.batches` / `.samples` count what this rank SAW (all batches of a plain loader, its own of a sharded one)."""
+
+    def __init__(self, dataloader, limit, rank, ws, sharded, progress=False, desc=""):
+        self.dl, self.limit, self.rank, self.ws, self.sharded, self.progress, self.desc = dataloader, limit, rank, ws, sharded, progress, desc
+        self.batches = self.samples = 0
+        self.sizes: List[Tuple[int, int]] = []                # (global batch index, images) of every batch seen
+
+    def __iter__(self):
+        local_limit = self.limit
+        if self.sharded and self.limit is not None:           # this rank's share of the first `limit` global batches
+            local_limit = len(range(self.rank, int(self.limit), self.ws))
+        for i, batch in iter_limited(self.dl, local_limit, self.progress, self.desc):
+            self.batches += 1
+            self.samples += int(batch["pixel_values"].size(0))
+            self.sizes.append((i * self.ws + self.rank if self.sharded else i, int(batch["pixel_values"].size(0))))
+            if self.sharded:
+                yield i * self.ws + self.rank, batch
+            elif _dist.owns(i, self.rank, self.ws):
+                yield i, batch
+
+
 def iter_limited(dataloader: Iterable, limit: Optional[int], progress: bool, desc: str):
     it = dataloader
     if progress:
@@ -192,7 +218,6 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
     sharded = sharded or bool(getattr(dataloader, "sharded", False))     # a loader that deals the batches itself says so (ssp2vit.local_data)
     chunk_images = DEFAULT_CHUNK_IMAGES if chunk_images is None else chunk_images
     local: List[Tuple[int, torch.Tensor]] = []
-    n_samples = n_batches = 0
     eng = None
     ch = None
 
@@ -206,13 +231,10 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
         if ramp:
             ch.capacity = ramp.pop(0)
 
-    for i, batch in iter_limited(dataloader, batch_limit, progress, "S1 activations"):
+    walk = _OwnedBatches(dataloader, batch_limit, rank, ws, sharded, progress, "S1 activations")
+    for gi, batch in walk:                                         # gi: global batch index
         px = batch["pixel_values"]
         n = int(px.size(0))
-        n_samples += n; n_batches += 1
-        gi = i * ws + rank if sharded else i                       # global batch index
-        if not sharded and not _dist.owns(i, rank, ws):
-            continue
         if eng is None or (callable(engine) and n > eng.max_images):
             if ch is not None and ch.items:
                 flush()
@@ -232,7 +254,15 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
         ch.add(gi, batch)
     if ch is not None and ch.items:
         flush()
+    return _reduce_scores(local, walk.batches, walk.samples, d_ints, score_chain, process_group, defer, sharded)
 
+
+def _reduce_scores(local, n_batches: int, n_samples: int, d_ints: Sequence[int], score_chain: str, process_group, defer: bool,
+                   sharded: bool):
+    """Per-batch score sums of this rank [(global batch index, f32 [L, ld])] -> the stage-1 importances: ONE all_gather of the vectors,
+    added in GLOBAL batch order on every rank (identical bits for every world size and packing), divided by the global sample count
+    (reference src/vit_pruning.py:154-157, :194-200).  n_batches / n_samples: what this rank saw (see _OwnedBatches)."""
+    rank, ws = _dist.world(process_group)
     if sharded and (ws > 1 or (_dist.FORCE_COLLECTIVES and _dist._initialised())):
         tot = torch.tensor([n_batches, n_samples], dtype=torch.int64, device=_dist._default_device(process_group))
         n_batches, n_samples = (int(v) for v in _dist.all_reduce_counts(tot, process_group).to("cpu"))
@@ -316,9 +346,7 @@ def _chunks(engine, dataloader, limit, progress, desc, rank, ws, chunk_images, c
         px_buf, lb_buf, count = ([px[k:]], [lb[k:]], count - k) if k < count else ([], [], 0)
         return out
 
-    for i, batch in iter_limited(dataloader, limit, progress, desc):
-        if not sharded and not _dist.owns(i, rank, ws):
-            continue
+    for _, batch in _OwnedBatches(dataloader, limit, rank, ws, sharded, progress, desc):
         px, labels = batch["pixel_values"], batch["labels"]
         if eng is None:
             need = max(chunk_images, int(px.size(0)))
@@ -378,6 +406,141 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
     return int(c[0]), int(c[1])
 
 
+def slab_rows(tokens: int, n: int, group: int) -> int:
+    """Rows one SLOT of n images takes in the slab layout with `group` images per slab, every slab padded (n a multiple of group):
+    slot s of a layer-major launch then begins at slab s * n / group of the launch's row map (csrc/common.hip.h RowMap)."""
+    mpad = (group * tokens + 255) // 256 * 256
+    return (n // group) * mpad
+
+
+def _search_chunk(eng, px, labels, n: int, L: int, cands: Sequence[int], removed: Sequence[int], counts_dev: torch.Tensor, *,
+                  slots: int, lm: bool, group: int = 0, score=None, aux_engine=None, aux_stream=None, aux_lead: float = 0.0,
+                  defer_tail: bool = False):
+    """One chunk of the depth search: the baseline and every candidate of `cands` over the n images `px` (a tensor or a list of
+    batches); correct counts are ADDED into counts_dev ([L + 1]: candidates, then the baseline).
+    `group` > 0: the streams are in the SLAB layout (one slab per dataloader batch of `group` images, n a multiple of it).
+    `score` = (site, chain): the baseline is the stage-1 pass too — its fc1 launches carry the hook (slot 0 of the layer-major launch
+    through ssp2_layers_prefix) and the per-batch score sums f32 [n / group, L, score_ld] are returned.
+    Returns (scores or None, tails or None): with `defer_tail` (scored layer-major chunks) the CLS-only tails — which only the counts
+    need — are handed back as a callable instead of being enqueued, so that a caller can send the finished scores on their way first."""
+    cand_set, removed_set = set(cands), set(removed)
+    removed = sorted(removed_set)
+    if score is not None and (removed or group <= 0 or n % group):
+        raise ValueError("a scored baseline is the DENSE model in whole slabs")
+    site, chain = score if score is not None else ("none", "fp32")
+    g = int(group)
+    kw = {"score_group": g} if g > 0 else {}                      # (a stand-in engine of the CPU tests knows no layouts)
+    tkw = {"group": g} if g > 0 else {}
+    rows = slab_rows(eng.tokens, n, g) if g > 0 else None
+    bs = eng.new_scores(n // g) if score is not None else None
+    xb = None
+    if lm and getattr(eng, "batch_lists", False):
+        # the embedding lands straight in slot 0 of the slot buffer (round 2 embedded into its own tensor and copied it over)
+        rows = eng.rows(n) if rows is None else rows
+        spare = 1 if score is not None else 0                 # one more slot: where the hooked LAST block of the baseline runs out of place
+        xb = torch.empty((slots + spare) * rows, eng.dim, dtype=torch.float32, device=eng.device)
+        if g > 0:
+            pad = rows - (eng.rows(n, g) if g < n else n * eng.tokens)      # the last slab's pad rows of every slot: finite values for the row-wise kernels
+            if pad:
+                xb.view(slots + spare, rows, eng.dim)[:, rows - pad:, :].zero_()
+        x = eng.embed(px, x=xb[:rows], group=g)
+    else:
+        x = eng.embed(px, group=g) if g > 0 else eng.embed(px)
+    if lm:
+        # Layer-major search: the baseline (slot 0) and the snapshots (the k-th candidate to start in slot k) sit
+        # side by side in one buffer, and at block l the baseline and every candidate already under way (c < l) run
+        # the block in ONE launch of (k + 1)*n images — same per-image arithmetic in the same order, l + 2 launches
+        # per block become 2, and the persistent GEMMs lose their partial last round ((l+1)*246.25 row panels
+        # instead of 246.25).  Candidate l itself runs block l alone (its attention is bypassed).  Blocks in
+        # `removed` (earlier rounds of the iterative search) are bypassed for every slot alike.  Needs an engine
+        # workspace for slots*n images.
+        if xb is None:
+            rows = x.shape[0]
+            xb = torch.empty(slots * rows, x.shape[1], dtype=x.dtype, device=x.device)
+            xb[:rows].copy_(x)
+        started = []
+        for l in range(L - 1):
+            k = len(started)
+            if l in cand_set:
+                # candidate l: block l without its attention, started STRAIGHT from the baseline's stream (slot 0 still holds
+                # the input of block l) into its own slot — the fc2 epilogue reads slot 0 and writes slot k + 1
+                # (ssp2_layers_from).  Round 2 copied the 194 MB stream into the slot first: 11 copies per step.
+                if OUT_OF_PLACE_START:
+                    eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l], x_in=xb[:rows], **kw)
+                else:
+                    xb[(k + 1) * rows:(k + 2) * rows].copy_(xb[:rows])
+                    eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l], **kw)
+            skip = [l] if l in removed_set else None
+            if score is not None:
+                eng.layers(xb[:(k + 1) * rows], (k + 1) * n, l, l + 1, skip, site, chain, bs, g, score_images=n)
+            else:
+                eng.layers(xb[:(k + 1) * rows], (k + 1) * n, l, l + 1, skip, **kw)
+            if l in cand_set:
+                started.append(l)
+        if score is not None:
+            # the hook of the LAST block, out of place into the spare slot (slot 0 stays what the tails read) and BEFORE the tails: the
+            # scores are then complete while the latency-bound tails still run — a caller's host mask step overlaps them
+            spare_x = xb[slots * rows:(slots + 1) * rows] if xb.shape[0] >= (slots + 1) * rows else torch.empty(rows, xb.shape[1], dtype=xb.dtype, device=xb.device)
+            eng.layers(spare_x, n, L - 1, L, None, site, chain, bs, g, scores_only=True, x_in=xb[:rows])
+
+        def tails():
+            # the baseline (slot 0) and every candidate under way meet the same last block and classifier: ONE tail over all the
+            # slots (ssp2_tail_slots) instead of one per slot — the tail's launches on n CLS rows are latency-bound, thirteen
+            # of them per chunk were ~3 % of the step.  Slot s is counted in slot_counts[s] and added to its candidate's entry.
+            if TAIL_SLOTS and getattr(eng, "batch_lists", False):
+                slot_counts = torch.zeros(len(started) + 1, dtype=torch.int64, device=counts_dev.device)
+                eng.tail(xb[:(len(started) + 1) * rows], n, removed, labels=labels, correct=slot_counts, slots=len(started) + 1, **tkw)
+                counts_dev.index_add_(0, _device_index([L] + started, counts_dev.device), slot_counts)
+            else:
+                eng.tail(xb[:rows], n, removed, labels=labels, correct=counts_dev[L:L + 1], **tkw)
+                for k, c in enumerate(started):
+                    eng.tail(xb[(k + 1) * rows:(k + 2) * rows], n, removed, labels=labels, correct=counts_dev[c:c + 1], **tkw)
+            if (L - 1) in cand_set:
+                eng.tail(xb[:rows], n, removed + [L - 1], labels=labels, correct=counts_dev[L - 1:L], **tkw)
+        if defer_tail:
+            return bs, tails
+        tails()
+        return bs, None
+    cache = {}
+    for l in range(L - 1):
+        if l in cand_set:
+            cache[l] = x.clone()
+        if score is not None:
+            eng.layers(x, n, l, l + 1, None, site, chain, bs, g)
+        else:
+            eng.layers(x, n, l, l + 1, removed, **kw)
+    # x now enters the last block: every pass finishes with the CLS-only tail, which leaves x untouched
+    eng.tail(x, n, removed, labels=labels, correct=counts_dev[L:L + 1], **tkw)
+    on_aux = set()
+    if aux_engine is not None and aux_stream is not None and n <= aux_engine.max_images:
+        load_main, load_aux = float(L - 1), float(aux_lead)          # greedy split, longest candidates first
+        for c in sorted(cand_set):
+            cost = float(L - 1 - c) + 0.2
+            if load_aux + cost < load_main:
+                on_aux.add(c); load_aux += cost
+            else:
+                load_main += cost
+        main = torch.cuda.current_stream(eng.device)
+        aux_stream.wait_stream(main)                                   # snapshots and labels are ready
+    for c in cands:
+        e, ctx = (aux_engine, torch.cuda.stream(aux_stream)) if c in on_aux else (eng, contextlib.nullcontext())
+        with ctx:
+            if c == L - 1:
+                e.tail(x, n, removed + [c], labels=labels, correct=counts_dev[c:c + 1], **tkw)
+                continue
+            xc = cache.pop(c)
+            if c in on_aux:
+                xc.record_stream(aux_stream)
+            e.layers(xc, n, c, L - 1, removed + [c], **kw)
+            e.tail(xc, n, removed + [c], labels=labels, correct=counts_dev[c:c + 1], **tkw)
+    if on_aux:
+        x.record_stream(aux_stream); labels.record_stream(aux_stream)
+        torch.cuda.current_stream(eng.device).wait_stream(aux_stream)
+    if score is not None:                  # the hook of the LAST block on the baseline's stream, which nothing reads any more
+        eng.layers(x, n, L - 1, L, None, site, chain, bs, g, scores_only=True)
+    return bs, None
+
+
 @torch.no_grad()
 def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional[int] = 5, process_group=None,
                         removed: Sequence[int] = (), candidates: Optional[Sequence[int]] = None,
@@ -417,89 +580,8 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
         if counts_dev is None:
             counts_dev = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
         n = int(labels.size(0))
-        lm = want_lm and eng.max_images >= slots * n
-        xb = None
-        if lm and getattr(eng, "batch_lists", False):
-            # the embedding lands straight in slot 0 of the slot buffer (round 2 embedded into its own tensor and copied it over)
-            rows0 = eng.rows(n)
-            xb = torch.empty(slots * rows0, eng.dim, dtype=torch.float32, device=eng.device)
-            x = eng.embed(px, x=xb[:rows0])
-        else:
-            x = eng.embed(px)
-        if lm:
-            # Layer-major search: the baseline (slot 0) and the snapshots (the k-th candidate to start in slot k) sit
-            # side by side in one buffer, and at block l the baseline and every candidate already under way (c < l) run
-            # the block in ONE launch of (k + 1)*n images — same per-image arithmetic in the same order, l + 2 launches
-            # per block become 2, and the persistent GEMMs lose their partial last round ((l+1)*246.25 row panels
-            # instead of 246.25).  Candidate l itself runs block l alone (its attention is bypassed).  Blocks in
-            # `removed` (earlier rounds of the iterative search) are bypassed for every slot alike.  Needs an engine
-            # workspace for slots*n images.
-            rows = x.shape[0]
-            if xb is None:
-                xb = torch.empty(slots * rows, x.shape[1], dtype=x.dtype, device=x.device)
-                xb[:rows].copy_(x)
-            started = []
-            for l in range(L - 1):
-                k = len(started)
-                if l in cand_set:
-                    # candidate l: block l without its attention, started STRAIGHT from the baseline's stream (slot 0 still holds
-                    # the input of block l) into its own slot — the fc2 epilogue reads slot 0 and writes slot k + 1
-                    # (ssp2_layers_from).  Round 2 copied the 194 MB stream into the slot first: 11 copies per step.
-                    if OUT_OF_PLACE_START:
-                        eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l], x_in=xb[:rows])
-                    else:
-                        xb[(k + 1) * rows:(k + 2) * rows].copy_(xb[:rows])
-                        eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l])
-                eng.layers(xb[:(k + 1) * rows], (k + 1) * n, l, l + 1, [l] if l in removed_set else None)
-                if l in cand_set:
-                    started.append(l)
-            # the baseline (slot 0) and every candidate under way meet the same last block and classifier: ONE tail over all the
-            # slots (ssp2_tail_slots) instead of one per slot — the tail's launches on n CLS rows are latency-bound, thirteen
-            # of them per chunk were ~3 % of the step.  Slot s is counted in slot_counts[s] and added to its candidate's entry.
-            if TAIL_SLOTS and getattr(eng, "batch_lists", False):
-                slot_counts = torch.zeros(len(started) + 1, dtype=torch.int64, device=counts_dev.device)
-                eng.tail(xb[:(len(started) + 1) * rows], n, removed, labels=labels, correct=slot_counts, slots=len(started) + 1)
-                counts_dev.index_add_(0, _device_index([L] + started, counts_dev.device), slot_counts)
-            else:
-                eng.tail(xb[:rows], n, removed, labels=labels, correct=counts_dev[L:L + 1])
-                for k, c in enumerate(started):
-                    eng.tail(xb[(k + 1) * rows:(k + 2) * rows], n, removed, labels=labels, correct=counts_dev[c:c + 1])
-            if (L - 1) in cand_set:
-                eng.tail(xb[:rows], n, removed + [L - 1], labels=labels, correct=counts_dev[L - 1:L])
-            total += n
-            continue
-        cache = {}
-        for l in range(L - 1):
-            if l in cands:
-                cache[l] = x.clone()
-            eng.layers(x, n, l, l + 1, removed)
-        # x now enters the last block: every pass finishes with the CLS-only tail, which leaves x untouched
-        eng.tail(x, n, removed, labels=labels, correct=counts_dev[L:L + 1])
-        on_aux = set()
-        if aux_engine is not None and aux_stream is not None and n <= aux_engine.max_images:
-            load_main, load_aux = float(L - 1), float(aux_lead)          # greedy split, longest candidates first
-            for c in sorted(cands):
-                cost = float(L - 1 - c) + 0.2
-                if load_aux + cost < load_main:
-                    on_aux.add(c); load_aux += cost
-                else:
-                    load_main += cost
-            main = torch.cuda.current_stream(eng.device)
-            aux_stream.wait_stream(main)                                   # snapshots and labels are ready
-        for c in cands:
-            e, ctx = (aux_engine, torch.cuda.stream(aux_stream)) if c in on_aux else (eng, contextlib.nullcontext())
-            with ctx:
-                if c == L - 1:
-                    e.tail(x, n, removed + [c], labels=labels, correct=counts_dev[c:c + 1])
-                    continue
-                xc = cache.pop(c)
-                if c in on_aux:
-                    xc.record_stream(aux_stream)
-                e.layers(xc, n, c, L - 1, removed + [c])
-                e.tail(xc, n, removed + [c], labels=labels, correct=counts_dev[c:c + 1])
-        if on_aux:
-            x.record_stream(aux_stream); labels.record_stream(aux_stream)
-            torch.cuda.current_stream(eng.device).wait_stream(aux_stream)
+        _search_chunk(eng, px, labels, n, L, cands, removed, counts_dev, slots=slots, lm=want_lm and eng.max_images >= slots * n,
+                      aux_engine=aux_engine, aux_stream=aux_stream, aux_lead=aux_lead)
         total += n
     if counts_dev is None:
         counts = torch.zeros(L + 2, dtype=torch.int64)
@@ -514,6 +596,174 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
         c = counts.to("cpu").tolist()
         return c[-2], c[:-2], c[-1]
     return finish if defer else finish()
+
+
+# what the last prune_pass of this process did (bench.py prints it: a run that silently fell back to the candidate-major order,
+# because its engine was sized without the slab padding, is then visible)
+PASS_STATS = {"fused_chunks": 0, "fused_layer_major": 0, "search_only_chunks": 0, "scores_only_launches": 0}
+
+
+def lm_capacity_images(tokens: int, slots: int, n: int, group: int) -> int:
+    """Engine capacity (images) whose workspace holds `slots` streams of n images side by side in the slab layout
+    (csrc/engine.hip: rows_cap = max_images * tokens + 16 * 256)."""
+    rows = slots * slab_rows(tokens, n, group)
+    return max(slots * n, -(-(rows - 16 * 256) // tokens))
+
+
+@torch.no_grad()
+def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int, *, score_limit: Optional[int] = None,
+               search_limit: Optional[int] = 5, score_chain: str = "fp32", process_group=None,
+               chunk_images: Optional[int] = None, eval_chunk_images: Optional[int] = None, defer: bool = False,
+               sharded: bool = False, candidates: Optional[Sequence[int]] = None, progress: bool = False,
+               batch_candidates="auto"):
+    """ONE walk over ONE loader for BOTH stages: the stage-1 scores (stage1_scores) and the depth search's counts
+    (depth_search_counts), with the search's dense baseline forward doubling as the stage-1 pass.
+
+    The reference's plug-in walks one loader with one batch_limit for both: `Auto2SSPInterface._compute_mlp_importance` hooks
+    `self.dl[:batch_limit]` (adaptation-for-Pures-framework/mask_conjunction.py:276-281), `_compute_att_depth_importance` evaluates the
+    dense model (:327) and every candidate (:345) on `self.dl[:batch_limit]` again; `fit()` runs both (:359-362) and the CLI builds
+    the object once (auto_2ssp.py:765-775).  The dense forward over those batches is computed twice there (and L more times with one
+    attention bypassed).  Here a batch that both stages want goes through ONE dense forward: it is laid out as its own 256-row-aligned
+    slab (what pins a sample's partial sums of squares, see stage1_scores), the fc1 launches of that baseline carry the stage-1 hook,
+    and the candidates of the layer-major search start from its per-block stream as before.  Scores are bit-identical to
+    stage1_scores (slab position) and counts to depth_search_counts (no result of a row depends on the launch it is part of).
+
+    `score_limit` / `search_limit`: GLOBAL batch limits of the two stages (None = the whole loader).  Batches inside both go through
+    the fused forward; batches only stage 1 wants get the scores-only forward, batches only the search wants the plain search.
+    A loader that reshuffles per epoch (the reference's calibration loader, auto_2ssp.py:348) is iterated ONCE and that one order
+    feeds both stages; the reference draws a fresh order per walk, so there the two stages see different random subsets.
+    Batches need "labels" wherever the search takes them.
+
+    Returns (scores, (baseline_correct, [candidate_correct], total)); with `defer=True` two zero-argument callables that wait."""
+    rank, ws = _dist.world(process_group)
+    sharded = sharded or bool(getattr(dataloader, "sharded", False))
+    L = depth
+    cands = list(range(L)) if candidates is None else [int(c) for c in candidates]
+    slots = 1 + sum(1 for c in set(cands) if c < L - 1)
+    want_lm = (batch_candidates is True or batch_candidates == "auto") and slots > 1
+    chunk_images = DEFAULT_CHUNK_IMAGES if chunk_images is None else chunk_images
+    eval_chunk = eval_chunk_images or DEFAULT_EVAL_CHUNK_IMAGES
+    limit = None if (score_limit is None or search_limit is None) else max(int(score_limit), int(search_limit))
+    walk = _OwnedBatches(dataloader, limit, rank, ws, sharded, progress, "2SSP pass")
+    for k_ in PASS_STATS:
+        PASS_STATS[k_] = 0
+    local: List[Tuple[int, torch.Tensor]] = []
+    seen_score = [0, 0]                      # batches / samples this rank SAW inside the score limit
+    state = {"eng": None, "counts": None, "total": 0, "s1": None, "lm_ok": False}
+    fused: List[Tuple[int, torch.Tensor, torch.Tensor, bool]] = []      # (global index, pixels, labels, scored?) of the open search chunk
+
+    def resolve(n: int):
+        base = max(chunk_images, n)
+        n_chunk = max(1, eval_chunk // n) * n
+        tokens = getattr(engine, "tokens", None)
+        if callable(engine):
+            need = base
+            per_image = getattr(engine, "bytes_per_image", None)
+            if want_lm and per_image is not None:
+                tk = tokens() if callable(tokens) else tokens
+                lm_imgs = lm_capacity_images(int(tk), slots, n_chunk, n) if tk else int(slots * n_chunk * 1.05) + 64
+                if lm_imgs * per_image() <= workspace_budget_bytes():
+                    need = max(need, lm_imgs)
+            eng = engine(need)
+        else:
+            eng = engine
+        state["eng"] = eng
+        state["counts"] = torch.zeros(L + 1, dtype=torch.int64, device=eng.device)
+        state["s1"] = _Chunker(min(eng.max_images, base), eng.device, max_batches=MAX_SLABS)
+        return eng
+
+    def fits_lm(eng, n: int, g: int) -> bool:
+        if not want_lm or eng.max_images < slots * n:
+            return False
+        if not getattr(eng, "prefix_scoring", False):
+            return True
+        return eng.max_images * eng.tokens + 16 * 256 >= slots * slab_rows(eng.tokens, n, g)
+
+    def run_pending():          # the CLS-only tails of the previous scored chunk (held back so that its scores could leave first)
+        t, state["tails"] = state.get("tails"), None
+        if t is not None:
+            t()
+
+    def flush_fused():
+        if not fused:
+            return
+        eng = state["eng"]
+        items = list(fused); fused.clear()
+        g = int(items[0][1].size(0))
+        n = sum(int(it[1].size(0)) for it in items)
+        scored = items[0][3]
+        as_list = BATCH_LISTS and getattr(eng, "batch_lists", False)
+        px = items[0][1] if len(items) == 1 else ([it[1] for it in items] if as_list else torch.cat([it[1] for it in items], 0))
+        labels = items[0][2] if len(items) == 1 else torch.cat([it[2] for it in items], 0)
+        run_pending()
+        if getattr(eng, "prefix_scoring", False):
+            if scored:
+                lm_now = fits_lm(eng, n, g)
+                PASS_STATS["fused_chunks"] += 1; PASS_STATS["fused_layer_major"] += int(lm_now)
+                bs, state["tails"] = _search_chunk(eng, px, labels, n, L, cands, (), state["counts"], slots=slots, lm=lm_now,
+                                                   group=g, score=(site, score_chain), defer_tail=True)
+                for k, it in enumerate(items):
+                    local.append((it[0], bs[k]))
+            else:
+                PASS_STATS["search_only_chunks"] += 1
+                _search_chunk(eng, px, labels, n, L, cands, (), state["counts"], slots=slots, lm=want_lm and eng.max_images >= slots * n)
+        else:
+            # an engine without the prefix hook (the stand-in engine of the CPU tests): two forwards, the same results
+            if scored:
+                vec = eng.forward_scores(px if not isinstance(px, list) else torch.cat(px, 0), site, score_chain, g)
+                for k, it in enumerate(items):
+                    local.append((it[0], vec[k]))
+            _search_chunk(eng, px, labels, n, L, cands, (), state["counts"], slots=slots, lm=want_lm and eng.max_images >= slots * n)
+        state["total"] += n
+
+    def flush_s1():
+        ch, eng = state["s1"], state["eng"]
+        if ch is None or not ch.items:
+            return
+        idxs, group, px, _ = ch.take(as_list=BATCH_LISTS and getattr(eng, "batch_lists", False))
+        vec = eng.forward_scores(px, site, score_chain, group)
+        PASS_STATS["scores_only_launches"] += 1
+        for k, i in enumerate(idxs):
+            local.append((i, vec[k]))
+
+    for gi, batch in walk:
+        n = int(batch["pixel_values"].size(0))
+        in_search = search_limit is None or gi < int(search_limit)
+        in_score = score_limit is None or gi < int(score_limit)
+        eng = state["eng"] or resolve(n)
+        if in_search:
+            if "labels" not in batch:
+                raise KeyError("prune_pass: a batch inside the search limit carries no 'labels'")
+            cap = min(max(1, eval_chunk // n) * n, eng.max_images)
+            if fused and (int(fused[0][1].size(0)) != n or fused[0][3] != in_score
+                          or sum(int(it[1].size(0)) for it in fused) + n > cap):
+                flush_fused()
+            fused.append((gi, _pixels_to_device(batch, eng.device), _to_device(batch["labels"], eng.device, torch.int64), in_score))
+        elif in_score:
+            flush_fused()
+            if state["s1"].full_for(n):
+                flush_s1()
+            state["s1"].add(gi, batch)
+    flush_fused()
+    flush_s1()
+    # what this rank saw inside the score limit (all batches of a plain loader, its own of a sharded one)
+    for gi_seen, n_seen in walk.sizes:
+        if score_limit is None or gi_seen < int(score_limit):
+            seen_score[0] += 1; seen_score[1] += n_seen
+    scores = _reduce_scores(local, seen_score[0], seen_score[1], d_ints, score_chain, process_group, defer, sharded)
+    run_pending()
+
+    if state["counts"] is None:
+        counts = torch.zeros(L + 2, dtype=torch.int64)
+    else:
+        counts = torch.cat([state["counts"], torch.full((1,), state["total"], dtype=torch.int64, device=state["counts"].device)])
+    if ws > 1 or (_dist.FORCE_COLLECTIVES and _dist._initialised()):
+        counts = _dist.all_reduce_counts(counts.to(_dist._default_device(process_group)), process_group)
+
+    def finish_search():
+        c = counts.to("cpu").tolist()
+        return c[-2], c[:-2], c[-1]
+    return (scores, finish_search) if defer else (scores, finish_search())
 
 
 def impacts_from_counts(base: int, cand: Sequence[int], total: int) -> List[float]:

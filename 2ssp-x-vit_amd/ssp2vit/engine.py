@@ -230,6 +230,7 @@ class VitEngine:
 
     # ------------------------------------------------------------------ the four device entry points
     batch_lists = True          # embed / forward_scores take a LIST of batches: each lands in its rows of x, nothing is concatenated
+    prefix_scoring = True       # layers(score_images=...) / tail(group=...): the search's baseline can carry the stage-1 hook (core.prune_pass)
 
     def embed(self, pixels, x: Optional[torch.Tensor] = None, group: int = 0) -> torch.Tensor:
         if isinstance(pixels, (list, tuple)):
@@ -265,20 +266,23 @@ class VitEngine:
     def layers(self, x: torch.Tensor, n: int, l_begin: int = 0, l_end: Optional[int] = None,
                attn_skip: Optional[Sequence[int]] = None, score_site: str = "none", score_chain: str = "fp32",
                batch_scores: Optional[torch.Tensor] = None, score_group: int = 0, scores_only: bool = False,
-               x_in: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+               x_in: Optional[torch.Tensor] = None, score_images: Optional[int] = None) -> Optional[torch.Tensor]:
         """Returns f32 [groups, depth, score_ld] when scoring (groups = ceil(n / score_group), 1 if score_group=0).
         `scores_only`: x is scratch afterwards — the last block stops behind its hooked activation (SSP2_SCORE_ONLY).
-        `x_in`: the stream entering block l_begin is read from there and left untouched (ssp2_layers_from); x receives the result."""
+        `x_in`: the stream entering block l_begin is read from there and left untouched (ssp2_layers_from); x receives the result.
+        `score_images`: only the leading images of the launch are hooked (whole slabs; ssp2_layers_prefix) — the search's baseline
+        doubling as the stage-1 pass; groups = ceil(score_images / score_group)."""
         l_end = self.depth if l_end is None else l_end
         site = SCORE_SITE[score_site] | (0x10 if (scores_only and SCORE_SITE[score_site]) else 0)
-        grp = n if (score_group <= 0 or score_group > n) else score_group
+        ns = n if score_images is None else int(score_images)
+        grp = ns if (score_group <= 0 or score_group > ns) else score_group
         if site and batch_scores is None:
-            batch_scores = self.new_scores((n + grp - 1) // grp)
+            batch_scores = self.new_scores((ns + grp - 1) // grp)
         self._bind_stream()
         if x_in is not None and (x_in.shape[0] < x.shape[0] or x_in.shape[1:] != x.shape[1:] or x_in.dtype != x.dtype or not x_in.is_contiguous()):
             raise ValueError("x_in must be a contiguous stream of the shape of x")
-        check(self.lib.ssp2_layers_from(self.h, _ptr(x_in), _ptr(x), n, l_begin, l_end, self._skip_array(attn_skip), site,
-                                        SCORE_CHAIN[score_chain], int(score_group), _ptr(batch_scores if site else None), self.score_ld))
+        check(self.lib.ssp2_layers_prefix(self.h, _ptr(x_in), _ptr(x), n, l_begin, l_end, self._skip_array(attn_skip), site,
+                                          SCORE_CHAIN[score_chain], int(score_group), ns, _ptr(batch_scores if site else None), self.score_ld))
         return batch_scores if site else None
 
     def head(self, x: torch.Tensor, n: int, labels: Optional[torch.Tensor] = None,
@@ -296,11 +300,12 @@ class VitEngine:
 
     def tail(self, x: torch.Tensor, n: int, attn_skip: Optional[Sequence[int]] = None,
              labels: Optional[torch.Tensor] = None, correct: Optional[torch.Tensor] = None, want_logits: bool = False,
-             want_pred: bool = False, slots: int = 1):
+             want_pred: bool = False, slots: int = 1, group: int = 0):
         """Last encoder block + head on the CLS rows only (x must hold the residual stream ENTERING the last block;
         it is not modified).  Same results, bit for bit, as layers(x, depth-1, depth) + head(x).
         `slots` > 1: x holds that many streams of n images side by side (ssp2_tail_slots); labels [n] are shared, `correct`
-        must have `slots` entries (slot s is counted in correct[s]), logits / pred cover slots * n images."""
+        must have `slots` entries (slot s is counted in correct[s]), logits / pred cover slots * n images.
+        `group` > 0: the streams are in the slab layout of `rows(slots * n, group)` (ssp2_tail_group)."""
         tot = n * int(slots)
         logits = torch.empty(tot, self.classes, dtype=torch.float32, device=self.device) if want_logits else None
         pred = torch.empty(tot, dtype=torch.int32, device=self.device) if want_pred else None
@@ -312,7 +317,7 @@ class VitEngine:
                 raise ValueError("`correct` needs one contiguous int64 entry per slot")
         skip_last = bool(self.absent[self.depth - 1]) or (attn_skip is not None and (self.depth - 1) in [int(i) for i in attn_skip])
         self._bind_stream()
-        check(self.lib.ssp2_tail_slots(self.h, _ptr(x), n, int(slots), int(skip_last), _ptr(logits), _ptr(pred), _ptr(labels),
+        check(self.lib.ssp2_tail_group(self.h, _ptr(x), n, int(slots), int(group), int(skip_last), _ptr(logits), _ptr(pred), _ptr(labels),
                                        _ptr(correct if labels is not None else None)))
         return logits, pred, correct
 

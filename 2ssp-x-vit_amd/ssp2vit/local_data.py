@@ -8,8 +8,8 @@ ToTensor -> Normalize chain, :290-301) in batches with the reference's loader se
   * test loader:         batch 64, NOT shuffled, test transform (no flip)
   * calibration loader:  batch 64, shuffled, TRAIN transform (random horizontal flip, p = 0.5)
 
-Shuffle and flips are drawn from `seed` and the epoch number (every `iter()` is an epoch, as with a DataLoader), identically on
-every rank; with `world > 1` a rank yields only the batches it owns (`dist.rank_batch_indices`: global batch b -> rank b % world),
+The shuffle is drawn from `seed` and the epoch number (every `iter()` is an epoch, as with a DataLoader), the flips once per loader
+from `seed` (the reference materialises its train transform in `datasets.map`, :334-336), identically on every rank; with `world > 1` a rank yields only the batches it owns (`dist.rank_batch_indices`: global batch b -> rank b % world),
 to be consumed with `sharded=True`.
 
 File formats (no pickles — `numpy.load(allow_pickle=False)`):
@@ -88,10 +88,16 @@ class Uint8BatchLoader:
         return len(_dist.rank_batch_indices(self.n, self.batch_size, self.rank, self.world, self.limit))
 
     def order(self, epoch: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(permutation of the n items, flip bit per ITEM) of one epoch — the same on every rank."""
+        """(permutation of the n items, flip bit per ITEM) of one epoch — the same on every rank.  The ORDER is redrawn per epoch
+        (DataLoader(shuffle=True), reference :348); the FLIPS are drawn once per loader from `seed`: the reference applies its train
+        transform inside `datasets.map(...)` (:334-336), which materialises it, so an image keeps its flip over every later pass."""
         g = torch.Generator().manual_seed(self.seed * 1000003 + epoch)
         perm = torch.randperm(self.n, generator=g) if self.shuffle else torch.arange(self.n)
-        flips = (torch.rand(self.n, generator=g) < 0.5).to(torch.uint8) if self.random_flip else torch.zeros(self.n, dtype=torch.uint8)
+        if self.random_flip:
+            gf = torch.Generator().manual_seed(self.seed * 1000003 + 500009)
+            flips = (torch.rand(self.n, generator=gf) < 0.5).to(torch.uint8)
+        else:
+            flips = torch.zeros(self.n, dtype=torch.uint8)
         return perm, flips
 
     def batch_items(self, epoch: int) -> List[torch.Tensor]:
@@ -105,21 +111,31 @@ class Uint8BatchLoader:
             self._pp = GpuPreprocessor(self.images.shape[1:3], self.out_size, self.mean, self.std, device=self.device)
         return self._pp
 
+    def peek_global(self, n_batches: int = 1) -> List[dict]:
+        """The first `n_batches` GLOBAL batches of the NEXT epoch — the same images on every rank, whatever it owns — without
+        advancing the epoch (fp8 calibration: every rank must measure the same images, or its e4m3 scales differ from its peers')."""
+        perm, flips = self.order(self.epoch)
+        idx = _dist.rank_batch_indices(self.n, self.batch_size, 0, 1, self.limit)[: int(n_batches)]
+        return [self._batch(perm[torch.tensor(ix, dtype=torch.int64)], flips) for ix in idx]
+
     def __iter__(self) -> Iterator[dict]:
         epoch, self.epoch = self.epoch, self.epoch + 1
         _, flips = self.order(epoch)
         for items in self.batch_items(epoch):
-            idx = items.numpy()
-            srt = np.argsort(idx, kind="stable")                      # one ascending pass over a memory-mapped file, then back in batch order
-            block = np.empty((len(idx),) + tuple(self.images.shape[1:]), dtype=np.uint8)
-            block[srt] = self.images[idx[srt]]
-            px = torch.from_numpy(block)
-            if self.pin:
-                px = px.pin_memory()
-            batch = {"pixel_values": px, "labels": self.labels[items]}
-            pp = self._preprocessor()
-            if pp is not None:
-                batch["preprocess"] = pp
-            if self.random_flip:
-                batch["hflip"] = flips[items]
-            yield batch
+            yield self._batch(items, flips)
+
+    def _batch(self, items: torch.Tensor, flips: torch.Tensor) -> dict:
+        idx = items.numpy()
+        srt = np.argsort(idx, kind="stable")                      # one ascending pass over a memory-mapped file, then back in batch order
+        block = np.empty((len(idx),) + tuple(self.images.shape[1:]), dtype=np.uint8)
+        block[srt] = self.images[idx[srt]]
+        px = torch.from_numpy(block)
+        if self.pin:
+            px = px.pin_memory()
+        batch = {"pixel_values": px, "labels": self.labels[items]}
+        pp = self._preprocessor()
+        if pp is not None:
+            batch["preprocess"] = pp
+        if self.random_flip:
+            batch["hflip"] = flips[items]
+        return batch

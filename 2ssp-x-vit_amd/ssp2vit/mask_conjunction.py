@@ -38,7 +38,7 @@ class PruningInterface:
 
 class Auto2SSPInterface(PruningInterface):
     def __init__(self, model, pruning_dataloader, device=None, importance_mode="copy", batch_limit=5,
-                 min_remaining=256, error_policy="raise", *, score_chain="fp32", process_group=None):
+                 min_remaining=256, error_policy="raise", *, score_chain="fp32", process_group=None, one_pass=True, score_batch_limit="same"):
         super().__init__(model, pruning_dataloader)
         self.att_prune_type = PruningTypes.DEPTH
         self.mlp_prune_type = PruningTypes.WIDTH
@@ -49,6 +49,8 @@ class Auto2SSPInterface(PruningInterface):
         self.error_policy = error_policy
         self.score_chain = score_chain
         self.process_group = process_group
+        self.score_batch_limit = score_batch_limit      # extension: a different batch limit for the stage-1 hook ("same": batch_limit, the reference's one rule)
+        self.one_pass = one_pass            # fit(): one dense pass over self.dl feeds both importances (False: two passes, as the reference runs them)
 
     def _num_blocks(self) -> int:
         return len(_vp._blocks(self.nn)[0])
@@ -57,7 +59,8 @@ class Auto2SSPInterface(PruningInterface):
         """All device work enqueued; the returned callable waits and hands back the CPU tensors."""
         if self.dl is not None:
             fin = _vp._compute_ffn_activation_importance(self.nn, self.dl, device=self.device,
-                                                         batch_limit=self.batch_limit, progress=False,
+                                                         batch_limit=self.batch_limit if self.score_batch_limit == "same" else self.score_batch_limit,
+                                                         progress=False,
                                                          score_chain=self.score_chain,
                                                          process_group=self.process_group,
                                                          defer=(self.score_chain == "fp32"))
@@ -101,10 +104,48 @@ class Auto2SSPInterface(PruningInterface):
     def _compute_att_depth_importance(self) -> torch.Tensor:
         return self._att_importance_deferred()()
 
+    def _both_deferred(self):
+        """One walk over self.dl for both importances (vit_pruning.importances_one_pass): the reference hooks self.dl[:batch_limit]
+        (:276-281) and evaluates the dense baseline on self.dl[:batch_limit] again (:327) — the same batches, the same dense forward.
+        None when the two do not share a loader pass (heuristic depth scores, no loader, bf16_ref chain without labels ...)."""
+        if self.dl is None or self.importance_mode.lower() == "heuristic" or not self.one_pass:
+            return None
+        try:
+            sc, se = _vp.importances_one_pass(self.nn, self.dl, self.device, self.batch_limit, score_limit=self.score_batch_limit,
+                                              score_chain=self.score_chain, process_group=self.process_group, defer=True)
+        except KeyError:                # a loader without labels cannot feed the search: the reference would fail there too; keep its order of failure
+            return None
+
+        def att():
+            base, cand, total = se()
+            baseline = float(base / max(1, total))
+            return torch.tensor([max(0.0, baseline - float(c / max(1, total))) for c in cand], dtype=torch.float32)
+
+        def mlp():
+            got = sc() if callable(sc) else sc
+            return [t.detach().to("cpu") for t in got]
+        return att, mlp
+
     def fit(self):
-        """Attention first, then MLP, as the reference orders them (:359-362) — but both stages are ENQUEUED before the
-        host waits for either: the two are independent (stage 2 evaluates the dense model), so the GPU never idles
-        between them and the engine (built once, with the layer-major search's workspace) serves both."""
+        """Attention first, then MLP, as the reference orders them (:359-362).  Both importances come from ONE walk over the
+        loader whose dense forward serves the stage-1 hook and the search's baseline alike (`one_pass`, default on); everything is
+        ENQUEUED before the host waits, and the engine (built once, with the layer-major search's workspace) serves both."""
+        both = None
+        try:
+            both = self._both_deferred()
+        except Exception:
+            if getattr(self, "error_policy", "raise") == "raise":
+                raise
+        if both is not None:
+            att, mlp = both
+            try:
+                self.att_importance = att()
+            except Exception:
+                if getattr(self, "error_policy", "raise") == "raise":
+                    raise
+                self.att_importance = self._heuristic()
+            self.mlp_importance = mlp()
+            return self.att_importance, self.mlp_importance
         att = self._att_importance_deferred()
         mlp = self._mlp_importance_deferred()
         self.att_importance = att()

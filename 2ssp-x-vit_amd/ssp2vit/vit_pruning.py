@@ -177,6 +177,7 @@ class _EngineFactory:
 
     def __init__(self, model, device):
         self.model, self.device = model, device
+        self.tokens = _tokens_of(model)
 
     def __call__(self, n: int):
         return engine_for(self.model, self.device, max_images=n)
@@ -323,6 +324,26 @@ def depth_search_counts(model, dataloader, device="cuda", batch_limit: Optional[
                                      batch_limit=batch_limit, process_group=process_group, removed=removed,
                                      candidates=candidates, defer=defer, chunk_images=chunk_images,
                                      batch_candidates=batch_candidates, sharded=sharded)
+
+
+@torch.no_grad()
+def importances_one_pass(vit_model, dataloader, device="cuda", batch_limit: Optional[int] = 5, *, score_limit="same",
+                         score_chain: str = "fp32", process_group=None, engine=None, defer: bool = False,
+                         sharded: bool = False, chunk_images: Optional[int] = None, eval_chunk_images: Optional[int] = None,
+                         batch_candidates="auto"):
+    """Both importances of `Auto2SSPInterface.fit()` from ONE walk over the loader (core.prune_pass): the dense forward of the
+    search's baseline is the stage-1 pass as well (reference: one loader, one batch_limit, two separate dense passes —
+    adaptation-for-Pures-framework/mask_conjunction.py:276-281, :327, :359-362).  `score_limit`: "same" = batch_limit (the plug-in's
+    rule), an int or None for a different stage-1 limit (batches beyond the search's get a scores-only forward).
+    Returns (scores, (baseline_correct, [candidate_correct], total)) — or, with defer=True, two callables that wait."""
+    vit_model.eval()
+    blocks, kind = _blocks(vit_model)
+    d_ints = [p[0].out_features for p in _gather_mlp_pairs(vit_model)]
+    site = getattr(vit_model, "ssp2_score_site", None) or _weights.score_site_for("timm" if kind == "timm" else "hf")
+    return _core.prune_pass(_engine_factory(vit_model, device, engine), dataloader, d_ints, site, len(blocks),
+                            score_limit=batch_limit if score_limit == "same" else score_limit, search_limit=batch_limit,
+                            score_chain=score_chain, process_group=process_group, chunk_images=chunk_images,
+                            eval_chunk_images=eval_chunk_images, defer=defer, sharded=sharded, batch_candidates=batch_candidates)
 
 
 class HFAttentionBypass(nn.Module):

@@ -450,7 +450,7 @@ def act_l2_figure(eng, batch, tokens, d_int, dev, n_images=512):
             "kernel": "act_l2_norms_kernel<bf16> + score_colsum_halves_kernel (standalone a2; 2 launches per call)"}
 
 
-def api_level(args, weights, calib, evalb, plan, dev, steps=3):
+def api_level(args, weights, calib, evalb, plan, dev, steps=3, search_batches=None):
     """The same prune through the reference-named API on a LIVE module that sits on the device (as the reference keeps
     it): Auto2SSPInterface importances (attention first, then MLP, both enqueued before either is waited for) ->
     prune_vit_mlp_width(precomputed_importance) -> prune_vit_attention_blocks(selected_indices).  The engine build
@@ -464,11 +464,18 @@ def api_level(args, weights, calib, evalb, plan, dev, steps=3):
         model = EngineViT(weights).to(dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        s2 = Auto2SSPInterface(model, evalb, device=dev, importance_mode="copy", batch_limit=len(evalb), min_remaining=512)
-        s1 = Auto2SSPInterface(model, calib, device=dev, batch_limit=None, min_remaining=512)
-        att_fin = s2._att_importance_deferred()                  # fit(): attention first (mask_conjunction.py:359-362) ...
-        mlp_fin = s1._mlp_importance_deferred()                  # ... then MLP; both enqueued, then awaited
-        att, mlp = att_fin(), mlp_fin()
+        if evalb is None:
+            # ONE interface over ONE loader, as the reference's CLI builds it (auto_2ssp.py:765-775): fit() takes both importances from one
+            # walk; the search takes the first `search_batches` batches, the stage-1 hook all of them (score_batch_limit, an extension)
+            iface = Auto2SSPInterface(model, calib, device=dev, importance_mode="copy", batch_limit=search_batches, min_remaining=512,
+                                      score_batch_limit=None)
+            att, mlp = iface.fit()
+        else:
+            s2 = Auto2SSPInterface(model, evalb, device=dev, importance_mode="copy", batch_limit=len(evalb), min_remaining=512)
+            s1 = Auto2SSPInterface(model, calib, device=dev, batch_limit=None, min_remaining=512)
+            att_fin = s2._att_importance_deferred()                  # fit(): attention first (mask_conjunction.py:359-362) ...
+            mlp_fin = s1._mlp_importance_deferred()                  # ... then MLP; both enqueued, then awaited
+            att, mlp = att_fin(), mlp_fin()
         res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[plan.per_block_neurons_to_prune] * B, min_remaining=512,
                                      strategy="l1", collect_masks=True, precomputed_importance=[x.to(torch.float32) for x in mlp])
         K = plan.blocks_to_prune
@@ -525,6 +532,10 @@ def main():
                          "so the roofline object is not a clean kernel figure)")
     ap.add_argument("--no-overlap-figure", action="store_true",
                     help="skip the secondary two-stream figure (profiled runs: its kernels would be counted with the step's)")
+    ap.add_argument("--two-pass", action="store_true",
+                    help="rounds 1-4: stage 1 and the depth search as two independent passes over DISJOINT calibration / evaluation sets. "
+                         "Default: the reference's one-loader semantics (mask_conjunction.py:276-281, :327) — the evaluation batches are the "
+                         "first --eval-batches calibration batches and ONE dense pass over them serves the stage-1 hook and the search's baseline")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="no GPU work: the ranks meet over gloo and rank 0 prints a line with the world size (CPU test of --gpus N)")
     ap.add_argument("--overlap-stage1", action="store_true",
@@ -609,6 +620,9 @@ def main():
     args.batch_candidates = not args.no_batch_candidates and not args.two_streams
     if args.batch_candidates:
         cap = max(cap, depth * eval_chunk)
+        if not args.two_pass and not (args.two_streams or args.overlap_stage1):
+            # one pass: the search's streams are in the slab layout of the stage-1 hook (every 64-image batch padded to 256 rows)
+            cap = max(cap, core.lm_capacity_images(tokens, depth, max(1, eval_chunk // args.batch) * args.batch, args.batch))
     eng = VitEngine(weights, device=dev, max_images=cap, precision=args.precision)
     # --two-streams: stage 1 (calibration scores) and stage 2 (depth search on the dense model) are independent, and so
     # are the search candidates: with a second engine workspace (weights uploaded twice, 173 MB) on a second HIP stream
@@ -636,15 +650,21 @@ def main():
         u8 = torch.randint(0, 256, (args.batch, img, img, 3), generator=g, device=dev, dtype=torch.uint8)
         return pp(u8), u8
 
+    one_pass = not args.two_pass and not second
     calib, evalb = [], []
-    for k in range(n_cal_b):
+
+    def teacher(px):
+        x = eng.embed(px); eng.layers(x, args.batch)
+        return eng.head(x, args.batch, want_pred=True)[1].long()              # teacher labels: dense model's own argmax
+
+    for k in range(max(n_cal_b, n_ev_b) if one_pass else n_cal_b):
         px, u8 = fresh_pixels(0, k * world + rank)
         calib.append({"pixel_values": px, "u8": u8})
-    for k in range(n_ev_b):
+        if one_pass and k < n_ev_b:                                            # ONE loader: its first batches are what the search evaluates
+            calib[-1]["labels"] = teacher(px)
+    for k in range(0 if one_pass else n_ev_b):
         px, u8 = fresh_pixels(1, k * world + rank)
-        x = eng.embed(px); eng.layers(x, args.batch)
-        _, pred, _ = eng.head(x, args.batch, want_pred=True)
-        evalb.append({"pixel_values": px, "labels": pred.long(), "u8": u8})     # teacher labels: dense model's own argmax
+        evalb.append({"pixel_values": px, "labels": teacher(px), "u8": u8})
 
     def as_loader(batches):
         out = []
@@ -663,24 +683,34 @@ def main():
 
     sdist.TIMING = pg is not None              # device time of the exchange steps, both configs
 
+    # GLOBAL batch limits of the two stages (this rank's k-th batch is global batch k * world + rank)
+    g_score_limit = tot_cal_b if args.config == 2 else world * n_cal_b
+    g_search_limit = tot_ev_b if args.config == 2 else world * n_ev_b
+
     def step(s1_eng=eng1, sd=side, share=args.two_streams):
         # both stages are enqueued before the host waits for either: the a7 mask step runs on the CPU while the GPU
         # is still searching (the two stages are independent: stage 2 evaluates the dense model)
-        if sd is None:
+        if one_pass and sd is None:
+            # ONE walk over ONE loader: the dense forward over the batches both stages take is the stage-1 pass AND the search's baseline
+            scores, search = core.prune_pass(eng, calib_loader, d_ints, "pre_gelu", depth, score_limit=g_score_limit,
+                                             search_limit=g_search_limit, score_chain="fp32", process_group=pg, chunk_images=calib_chunk,
+                                             eval_chunk_images=eval_chunk, defer=True, sharded=True, batch_candidates=args.batch_candidates)
+        elif sd is None:
             scores = core.stage1_scores(s1_eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
-                                        chunk_images=calib_chunk, defer=True, sharded=True)
+                                        chunk_images=calib_chunk, defer=True, sharded=True, batch_limit=g_score_limit if one_pass else None)
         else:
             sd.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(sd):
                 scores = core.stage1_scores(s1_eng, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg,
-                                            chunk_images=calib_chunk, defer=True, sharded=True)
+                                            chunk_images=calib_chunk, defer=True, sharded=True, batch_limit=g_score_limit if one_pass else None)
         # the side stream also takes a share of the search candidates behind its stage-1 launch (lead ~ the stage-1
         # work expressed in block passes of the search chunk)
-        search = core.depth_search_counts(eng, eval_loader, depth, batch_limit=None, process_group=pg,
-                                          chunk_images=eval_chunk, defer=True,
-                                          aux_engine=s1_eng if share else None, aux_stream=sd if share else None,
-                                          aux_lead=n_calib * depth / max(1, eval_chunk),
-                                          batch_candidates=args.batch_candidates, sharded=True)
+        if not (one_pass and sd is None):
+            search = core.depth_search_counts(eng, calib_loader if one_pass else eval_loader, depth, batch_limit=g_search_limit if one_pass else None,
+                                              process_group=pg, chunk_images=eval_chunk, defer=True,
+                                              aux_engine=s1_eng if share else None, aux_stream=sd if share else None,
+                                              aux_lead=n_calib * depth / max(1, eval_chunk),
+                                              batch_candidates=args.batch_candidates, sharded=True)
         imps = scores()
         all_masks = []
         for p in plans:                                                   # a7 mask step per target (host, 12 x 3072)
@@ -741,7 +771,8 @@ def main():
         families = roofline_by_family(pall.by_class, args.precision)
     # stage-1-only rate (secondary figure, separate timed loop so the headline region stays untouched)
     sync_all(); t1 = time.perf_counter()
-    core.stage1_scores(eng1, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg, chunk_images=calib_chunk, sharded=True)
+    core.stage1_scores(eng1, calib_loader, d_ints, "pre_gelu", score_chain="fp32", process_group=pg, chunk_images=calib_chunk, sharded=True,
+                       batch_limit=g_score_limit if one_pass else None)
     sync_all(); s1_s = time.perf_counter() - t1
 
     # secondary figure: the same step with stage 1 on a second HIP stream (own engine workspace) beside the layer-major search —
@@ -769,6 +800,8 @@ def main():
         value = units_step * args.steps / elapsed
         tail = 2.0 * dim / (4 * dim + 2 * d_int + 2 * tokens)                            # cost of the CLS-only last block / a full block
         executed = calib_total * depth + eval_total * ((depth - 1) + (depth - 1) * depth // 2 + (depth + 1) * tail)   # block passes per step
+        if one_pass:       # the baseline's dense pass IS the stage-1 pass of those images (its last block runs once more, hooked, beside the CLS-only tail)
+            executed -= min(calib_total, eval_total) * (depth - 1)
         reference_equiv = calib_total * depth + eval_total * depth * (depth + 1)
         tdesc = ", ".join(f"{t} (K={p.blocks_to_prune}, t={p.per_block_neurons_to_prune})" for t, p in zip(targets, plans))
         per = "in total over the ranks" if args.config == 2 else "/GPU"
@@ -781,8 +814,10 @@ def main():
             "data": ("synthetic" + (", uint8 HWC through the GPU input pipeline" if args.uint8 else "")
                      + (", pinned host batches copied over PCIe inside the timed region" if args.host_inputs else "")),
             "config": {"workload": f"{args.model}, {calib_total if args.config == 2 else n_calib} calib images {per}, full 2SSP @ {tdesc}, "
-                                   f"one-shot depth search over {eval_total if args.config == 2 else n_eval} eval images {per}, batch {args.batch}, "
-                                   f"select + apply into a pruned engine inside the step",
+                                   f"one-shot depth search over {eval_total if args.config == 2 else n_eval} eval images {per}"
+                                   + (" = the FIRST batches of the calibration loader (the reference's one-loader semantics, mask_conjunction.py:276-281, :327: "
+                                      "one dense pass over them serves the stage-1 hook and the search's baseline)" if one_pass else " (a disjoint set, two passes)")
+                                   + f", batch {args.batch}, select + apply into a pruned engine inside the step",
                        "baseline_config": f"BASELINE.json configs[{args.config}]",
                        "weights": "random-init trunc-normal(0.02), fc1 rows log-uniform x[1/4,4], seed 0",
                        "parallelism": f"dp{world} (batches dealt round-robin, every rank's loader yields only its own, weights replicated)"},
@@ -792,6 +827,8 @@ def main():
             "selected_blocks": out[3][targets.index(args.target)] if args.target in targets else out[3][0],
             "selected_blocks_per_target": {str(t): b for t, b in zip(targets, out[3])},
             "pruned_neurons_per_block": plan.per_block_neurons_to_prune,
+            "passes": "one (stage-1 hook on the search's baseline forward)" if one_pass else "two",
+            "pass_stats": dict(core.PASS_STATS) if one_pass else None,
             "streams": 2 if (args.two_streams or args.overlap_stage1) else 1, "stage1_beside_search": bool(args.overlap_stage1), "search": "layer-major" if args.batch_candidates else "candidate-major",
         }
         if one_card:
@@ -845,8 +882,11 @@ def main():
             for t in twins:
                 t.close()
             torch.cuda.empty_cache()
-            api_calib = [{"pixel_values": b["pixel_values"]} for b in calib_loader]
-            line["api"] = api_level(args, weights, api_calib, eval_loader, plan, dev)
+            if one_pass:
+                line["api"] = api_level(args, weights, calib_loader, None, plan, dev, search_batches=n_ev_b)
+            else:
+                api_calib = [{"pixel_values": b["pixel_values"]} for b in calib_loader]
+                line["api"] = api_level(args, weights, api_calib, eval_loader, plan, dev)
             line["api"]["vs_core_step"] = round(line["api"]["prune_time_s"] / line["prune_time_s"], 3)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, weights, n_eval, n_calib)

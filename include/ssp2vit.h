@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SSP2_ABI_VERSION 3
+#define SSP2_ABI_VERSION 4
 
 enum {
   SSP2_OK = 0,
@@ -168,6 +168,16 @@ int ssp2_layers(ssp2_handle h, float* x_dev, int n, int l_begin, int l_end, cons
 int ssp2_layers_from(ssp2_handle h, const float* x_in_dev, float* x_dev, int n, int l_begin, int l_end, const uint8_t* attn_skip,
                      int score_site, int score_chain, int score_group, float* batch_scores_dev, int score_ld);
 
+/* The same with the stage-1 hook on the LEADING score_images images of the launch only (score_images == n: ssp2_layers_from).
+ * score_images < n needs the slab layout (0 < score_group < n) and a whole number of slabs.  This is how ONE dense pass serves both
+ * stages: the reference's Auto2SSPInterface walks one loader with one batch_limit for the stage-1 scores and for the search's baseline
+ * (adaptation-for-Pures-framework/mask_conjunction.py:276-281, :327, :345); here the baseline of the layer-major search sits in the
+ * leading slabs of the launch and is hooked, the candidates' streams behind it are not.  Scores and streams are the bits of the
+ * separate calls (a row's arithmetic does not depend on the launch it is part of; a slab's position pins its partial sums).
+ *   batch_scores_dev f32 [ceil(score_images/score_group), depth, score_ld] */
+int ssp2_layers_prefix(ssp2_handle h, const float* x_in_dev, float* x_dev, int n, int l_begin, int l_end, const uint8_t* attn_skip,
+                       int score_site, int score_chain, int score_group, int score_images, float* batch_scores_dev, int score_ld);
+
 /* a3 tail + a4: final LayerNorm on the CLS rows, classifier, first-max-index argmax (torch.argmax rule),
  * comparison with labels.  Any of logits_dev [n,classes] f32, pred_dev [n] i32, labels_dev [n] i64 +
  * correct_dev [1] i64 (ACCUMULATED into, caller zeroes) may be NULL. */
@@ -187,6 +197,11 @@ int ssp2_tail(ssp2_handle h, const float* x_dev, int n, int attn_skip_last, floa
  * labels_dev [n_slot] is shared by the slots; correct_dev [slots] (int64, accumulated); logits_dev / pred_dev [slots * n_slot, ...]. */
 int ssp2_tail_slots(ssp2_handle h, const float* x_dev, int n_slot, int slots, int attn_skip_last, float* logits_dev, int32_t* pred_dev,
                     const int64_t* labels_dev, int64_t* correct_dev);
+
+/* ... and for streams in the SLAB layout (group as in ssp2_rows; n_slot a multiple of group when slots > 1, so that slot s begins at slab
+ * s * n_slot / group): the tail of a search whose baseline was laid out for the stage-1 hook (ssp2_layers_prefix).  group <= 0: ssp2_tail_slots. */
+int ssp2_tail_group(ssp2_handle h, const float* x_dev, int n_slot, int slots, int group, int attn_skip_last, float* logits_dev,
+                    int32_t* pred_dev, const int64_t* labels_dev, int64_t* correct_dev);
 
 /* a8 on the device: keep only the listed FFN neurons of block `layer` — rows of fc1 (+bias) and
  * columns of fc2 are gathered in HBM (src/vit_pruning.py:297-311 does `W_int[keep]`, `B_int[keep]`, `W_out[:,keep]`

@@ -1906,7 +1906,7 @@ def test_tail_over_all_slots_gives_the_per_slot_tails_integers_and_logits(gpu):
 
 @pytest.mark.timeout(900)
 def test_two_and_three_ranks_sharing_the_card_equal_the_single_rank_result(gpu, tmp_path):
-    """SURVEY §8(e) on hardware, as far as one card allows: P = 2 and P = 3 processes, each with its own VitEngine on cuda:0, are
+    """(Round 5: also the ONE-PASS prune of core.prune_pass, and a global batch limit on sharded loaders.)  SURVEY §8(e) on hardware, as far as one card allows: P = 2 and P = 3 processes, each with its own VitEngine on cuda:0, are
     dealt the batches they own (batch b -> rank b % P; ragged last batches; with P = 3 a rank owns ONE eval batch) and run the
     product's sharded stage 1 (both chains) + one-shot depth search + top-1, exchanging over gloo (RCCL refuses two ranks on one
     device; the collectives are the same calls, the tensors take `dist.device_for_backend`'s host route).  Every rank's scores,
@@ -1927,10 +1927,22 @@ def test_two_and_three_ranks_sharing_the_card_equal_the_single_rank_result(gpu, 
         x = eng.embed(part); eng.layers(x, part.shape[0])
         labels.append(eng.head(x, part.shape[0], want_pred=True)[1].long().cpu())
     labels = torch.cat(labels); labels[::7] = (labels[::7] + 1) % 1000
+    labels_cal = []
+    for s in range(0, n_cal, batch):                                  # ... and for the calibration images: the one-pass prune searches on those
+        part = px[s:min(s + batch, n_cal)].to(gpu)
+        x = eng.embed(part); eng.layers(x, part.shape[0])
+        labels_cal.append(eng.head(x, part.shape[0], want_pred=True)[1].long().cpu())
+    labels_cal = torch.cat(labels_cal); labels_cal[::5] = (labels_cal[::5] + 1) % 1000
     eng.close()
-    data = {"px": px, "labels": labels, "batch": batch, "depth": 12, "d_int": 768, "n_calib": n_cal, "n_eval": n_ev, "model": model, "cap": 12 * batch}
-    ref = W.run(lambda: W.make_engine(model, 12 * batch), data, 0, 1, None, False)
+    from ssp2vit import core
+    cap = core.lm_capacity_images(197, 12, batch, batch)
+    data = {"px": px, "labels": labels, "batch": batch, "depth": 12, "d_int": 768, "n_calib": n_cal, "n_eval": n_ev, "model": model, "cap": cap,
+            "labels_cal": labels_cal, "search_limit": 3}
+    ref = W.run(lambda: W.make_engine(model, cap), data, 0, 1, None, False)
     assert ref["total"] == n_ev and 0 < ref["base"] < n_ev and len(set(ref["cand"])) > 1
+    # one rank: ONE pass == the two passes (scores over all 5 calibration batches, the search over the first 3 GLOBAL batches)
+    assert all(torch.equal(a, b) for a, b in zip(ref["one_imps"], ref["imps"])) and ref["one_counts"] == ref["two_counts"]
+    assert ref["one_counts"][2] == 3 * batch and 0 < ref["one_counts"][0] < 3 * batch
     path = str(tmp_path / "data.pt")
     torch.save(data, path)
     for world in (2, 3):
@@ -1944,6 +1956,13 @@ def test_two_and_three_ranks_sharing_the_card_equal_the_single_rank_result(gpu, 
             for a, b in zip(res["imps_bf"], ref["imps_bf"]):
                 assert a.dtype == b.dtype and torch.equal(a, b), (world, r)
             assert (res["base"], res["cand"], res["total"], res["top1"]) == (ref["base"], ref["cand"], ref["total"], ref["top1"]), (world, r)
+            # the one-pass prune at P ranks: the single rank's scores and counts; a GLOBAL batch limit on sharded loaders covers the same
+            # 3 batches at every world size (it used to count per rank)
+            for a, b in zip(res["one_imps"], ref["imps"]):
+                assert torch.equal(a, b), (world, r)
+            assert res["one_counts"] == ref["one_counts"] == res["two_counts"], (world, r)
+            for a, b in zip(res["imps_lim"], ref["imps_lim"]):
+                assert torch.equal(a, b), (world, r)
             assert res["stats"]["batches_owned"] > 0 and res["stats"]["exchanges"] >= 2
 
 

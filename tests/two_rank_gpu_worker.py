@@ -25,8 +25,19 @@ def run(engine_factory, data, rank, world, process_group, sharded):
     imps_bf = core.stage1_scores(eng, calib, [d_int] * depth, "post_gelu", score_chain="bf16_ref", **kw)
     base, cand, total = core.depth_search_counts(eng, evalb, depth, batch_limit=None, **kw)
     top1 = core.top1_counts(eng, evalb, **kw)
-    return {"imps": [t.cpu() for t in imps], "imps_bf": [t.cpu() for t in imps_bf], "base": int(base), "cand": [int(c) for c in cand],
-            "total": int(total), "top1": tuple(int(v) for v in top1), "stats": dict(D.STATS)}
+    out = {"imps": [t.cpu() for t in imps], "imps_bf": [t.cpu() for t in imps_bf], "base": int(base), "cand": [int(c) for c in cand],
+           "total": int(total), "top1": tuple(int(v) for v in top1)}
+    if "labels_cal" in data:
+        # ONE pass for both stages over the calibration loader (core.prune_pass): the search takes its first `search_limit` GLOBAL batches
+        calib_l = [{"pixel_values": px[ix], "labels": data["labels_cal"][ix]} for ix in cal_ix]
+        lim = int(data["search_limit"])
+        s1, (b1, c1, t1) = core.prune_pass(eng, calib_l, [d_int] * depth, "pre_gelu", depth, score_limit=None, search_limit=lim, **kw)
+        b2, c2, t2 = core.depth_search_counts(eng, calib_l, depth, batch_limit=lim, **kw)          # the same search, its own pass
+        s3 = core.stage1_scores(eng, calib_l, [d_int] * depth, "pre_gelu", batch_limit=lim, **kw)   # a GLOBAL limit on a sharded loader
+        out.update(one_imps=[t.cpu() for t in s1], one_counts=(int(b1), [int(c) for c in c1], int(t1)),
+                   two_counts=(int(b2), [int(c) for c in c2], int(t2)), imps_lim=[t.cpu() for t in s3])
+    out["stats"] = dict(D.STATS)
+    return out
 
 
 def make_engine(model, cap):
