@@ -600,7 +600,8 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
 
 # what the last prune_pass of this process did (bench.py prints it: a run that silently fell back to the candidate-major order,
 # because its engine was sized without the slab padding, is then visible)
-PASS_STATS = {"fused_chunks": 0, "fused_layer_major": 0, "search_only_chunks": 0, "scores_only_launches": 0}
+PASS_STATS = {"fused_chunks": 0, "fused_layer_major": 0, "search_only_chunks": 0, "scores_only_launches": 0,
+              "score_batches_owned": 0, "search_batches_owned": 0}      # the last two: 0 on a rank that idles in that stage (fewer batches than ranks)
 
 
 def lm_capacity_images(tokens: int, slots: int, n: int, group: int) -> int:
@@ -731,6 +732,7 @@ def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int,
         in_search = search_limit is None or gi < int(search_limit)
         in_score = score_limit is None or gi < int(score_limit)
         eng = state["eng"] or resolve(n)
+        PASS_STATS["score_batches_owned"] += int(in_score); PASS_STATS["search_batches_owned"] += int(in_search)
         if in_search:
             if "labels" not in batch:
                 raise KeyError("prune_pass: a batch inside the search limit carries no 'labels'")

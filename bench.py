@@ -759,6 +759,7 @@ def main():
         # one line per rank on stderr: a failed or slow multi-rank run is then readable from the tail of the driver's log
         print(sdist.rank_summary({"local_ms_per_step": round(elapsed / args.steps * 1e3, 3), "steps": args.steps,
                                   "calib_batches": n_cal_b, "eval_batches": n_ev_b,
+                                  **({"pass": ",".join(f"{k}={v}" for k, v in core.PASS_STATS.items())} if one_pass else {}),
                                   "collective_ms_per_step": {k: round(v / max(1, args.steps), 3) for k, v in (coll or {}).items()}}),
               file=sys.stderr, flush=True)
 

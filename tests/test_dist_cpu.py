@@ -105,11 +105,23 @@ def _run_all(process_group=None, sharded=False):
         batches = [{"pixel_values": px_all[ix], "labels": lb_all[ix]} for ix in mine]
     kw = dict(engine=eng, process_group=process_group, sharded=sharded)
     imps = vp._compute_ffn_activation_importance(model, batches, device="cpu", **kw)
-    lim = 3 if not sharded else None            # a batch limit counts LOCAL batches in sharded mode: not comparable
-    imps3 = vp._compute_ffn_activation_importance(model, batches, device="cpu", batch_limit=lim, **kw)
+    # a batch limit is GLOBAL in both loader modes (round 5; a sharded loader used to count it per rank — ADVICE r04)
+    imps3 = vp._compute_ffn_activation_importance(model, batches, device="cpu", batch_limit=3, **kw)
     counts = vp.depth_search_counts(model, batches, "cpu", None, **kw)
     top1 = vp._top1_counts(model, batches, "cpu", None, **kw)
-    return imps, imps3, counts, top1
+    # ... and the same limit on the two integer loops, and ONE pass for both stages (core.prune_pass through the reference-named wrapper)
+    counts3 = vp.depth_search_counts(model, batches, "cpu", 3, **kw)
+    top3 = vp._top1_counts(model, batches, "cpu", 3, **kw)
+    one = vp.importances_one_pass(model, batches, "cpu", 3, score_limit=None, **kw)
+    return imps, imps3, counts, top1, counts3, top3, one
+
+
+def _check_one_pass(res):
+    """ONE pass (scores over all 5 batches, the search over the first 3) == the separate passes of the same run."""
+    imps, _, _, _, counts3, _, one = res
+    for a, b in zip(one[0], imps):
+        assert torch.equal(a, b)
+    assert tuple(one[1]) == tuple(counts3)
 
 
 def _worker(rank, world, port, out_dir, sharded=False):
@@ -131,13 +143,16 @@ def test_two_rank_gloo_results_equal_single_process(tmp_path):
     torch.set_num_threads(2)
     ref = _run_all()
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    _check_one_pass(ref)
     for r in range(2):
-        imps, imps3, counts, top1 = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        imps, imps3, counts, top1, counts3, top3, one = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
         for a, b in zip(imps, ref[0]):
             assert torch.equal(a, b)                            # bitwise: global batch order, not arrival order
         for a, b in zip(imps3, ref[1]):
             assert torch.equal(a, b)
         assert counts == ref[2] and top1 == ref[3]
+        assert counts3 == ref[4] and top3 == ref[5]
+        _check_one_pass((imps, imps3, counts, top1, counts3, top3, one))
     assert ref[2][2] == 19 and ref[3][1] == 19                  # every image counted exactly once
 
 
@@ -151,12 +166,14 @@ def test_four_rank_gloo_ragged_ownership_equals_single_process(tmp_path, sharded
     ref = _run_all()
     mp.spawn(_worker, args=(4, _free_port(), str(tmp_path), sharded), nprocs=4, join=True)
     for r in range(4):
-        imps, imps3, counts, top1 = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        imps, imps3, counts, top1, counts3, top3, one = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
         for a, b in zip(imps, ref[0]):
             assert torch.equal(a, b)
-        for a, b in zip(imps3, ref[1] if not sharded else ref[0]):
+        for a, b in zip(imps3, ref[1]):                         # limit 3 = the first three GLOBAL batches, plain and sharded loaders alike
             assert torch.equal(a, b)
         assert counts == ref[2] and top1 == ref[3]
+        assert counts3 == ref[4] and top3 == ref[5] and counts3[2] == 12
+        _check_one_pass((imps, imps3, counts, top1, counts3, top3, one))
     assert ref[2][2] == 19
 
 
