@@ -53,6 +53,9 @@
 #ifndef GEMM_NT
 #define GEMM_NT 0
 #endif
+#ifndef GEMM_MFMA16
+#define GEMM_MFMA16 0
+#endif
 #if GEMM_NT == 2
 #define GLDS_A glds16_nt
 #define ST_OUT(p, v) (*(p) = (v))
@@ -605,6 +608,21 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
               ga[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
           } else {
+#if GEMM_MFMA16 == 1
+          // TIMING PROBE (tools/gemm_bench -DGEMM_MFMA16=1 only; results are NOT valid): the unit's 32 k-elements as ONE step of
+          // v_mfma_f32_16x16x32_bf16 — lane -> row (lane & 15) of a 16-row fragment, 16-byte chunk 4 * half + (lane >> 4); the
+          // swizzle (row >> 1) & 7 keeps every 16-lane group of the ds_read_b128 on 16 distinct 16-byte slots.  12 reads per unit, as before.
+          {
+            const int l15 = lane & 15, lq = lane >> 4;
+            const int o = ((4 * half + lq) ^ ((l15 >> 1) & 7)) << 4;
+            const char* Bs16 = smem + sb + (wn * 64 + l15) * 128 + o;
+            const char* As16 = smem + sa + (wm * 128 + l15) * 128 + o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fb[i >> 1][i & 1] = *(const bf16x8*)(Bs16 + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i >> 2][i & 3] = *(const bf16x8*)(As16 + i * 2048);
+          }
+#else
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             const int o = t16[2 * half + s2];
@@ -613,6 +631,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < C::TM; ++i) fa[s2][i] = *(const bf16x8*)(As + o + i * 4096);
           }
+#endif
           }
         }
         if (PP_NL > 0 && dma_on && early_ok) {
@@ -663,6 +682,31 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
 #pragma unroll
             for (int b = 0; b < C::TN; ++b) asm volatile("" : "+v"(acc[a][b]));
         } else
+#if GEMM_MFMA16 == 1
+        {
+          // 32 MFMAs of 16 cycles: 16-row fragment tm of the activations x 16-row fragment tn of the weights; accumulator (tm, tn) lives in
+          // quad (tm & 1) * 2 + (tn & 1) of acc[tm >> 1][tn >> 1] (probe: the epilogue's lane map does not apply).  A DMA piece behind
+          // every eighth MFMA = the 128-cycle cadence of the 32x32x16 loop.
+#pragma unroll
+          for (int tm = 0; tm < 8; ++tm) {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+              f32x16& A_ = acc[tm >> 1][tn >> 1];
+              constexpr int dummy = 0; (void)dummy;
+              const int j = (tm & 1) * 2 + (tn & 1);
+              f32x4 c4; c4.x = A_[4 * j]; c4.y = A_[4 * j + 1]; c4.z = A_[4 * j + 2]; c4.w = A_[4 * j + 3];
+              c4 = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn >> 1][tn & 1], fa[tm >> 2][tm & 3], c4, 0, 0, 0)
+                        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[tm >> 2][tm & 3], fb[tn >> 1][tn & 1], c4, 0, 0, 0);
+              A_[4 * j] = c4.x; A_[4 * j + 1] = c4.y; A_[4 * j + 2] = c4.z; A_[4 * j + 3] = c4.w;
+            }
+            if (!(tm & 1)) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (dma_on && !(PP_NL > 0 && early_ok && (tm >> 1) < PP_NL)) piece(tm >> 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+#else
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -678,6 +722,7 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
               __builtin_amdgcn_sched_barrier(0);
             }
           }
+#endif
         if (half == 0 && kt < 6) TSTAMP(5 + 6 * kt);
         if (half == 1 && !wm) {     // g0: end of phase 4kt+3
           if constexpr (SLOT != 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + SLOT_OPS) : "memory");

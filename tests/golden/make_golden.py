@@ -256,6 +256,176 @@ def vit_deep_case(name, tag, n_per_batch, targets, layout="timm"):
           f"distinct bf16 scores in block 0: {len(set(imps[0].float().tolist()))}; {time.time() - t0:.0f} s", flush=True)
 
 
+# ----------------------------------------------------------------------------------------------------------------------------
+# DECISIVE stage-2 fixtures.  With a random classifier head over 1000 classes a random-init ViT's logits are
+# flat (max |logit| ~ 2.4, top-2 gaps of a few hundredths): a third of the images sit on a near-tie that ANY implementation's rounding
+# decides, so counts could only be compared within a band.  Scaling the head does not help (margins and errors scale alike).  What
+# helps is a head DESIGNED on the model's own features, which the reference then runs as it would run any head:
+#   * label class of image i (class i):    w = a * unit(f_i - mean f),  bias cancels the mean  -> own logit a |d_i| ~ 3, others ~ +-0.3
+#   * distractor class of image i (n + i): the label row + b * v_i, where v_i is the minimum-norm direction with
+#         v_i . (f_i under bypass c  -  f_i dense) = 1 for the candidates c that shall flip image i, 0 for the others,
+#         v_i . (f_j - f_i) = 0 for the other images j (and, where the dimension allows, v_i . (their bypass shifts) = 0),
+#     and a bias that puts it b / 2 BELOW the label on the dense model: under candidate c it ends b / 2 above (flip) or b / 2 below (keep).
+#   * every other class: zero row, bias -5.
+# The bypass shifts |f_c - f| are 2 .. 19 against a bf16-vs-fp32 feature discrepancy of 0.26 (ViT-L/16), the system is well conditioned
+# (|v| ~ 1), so every (pass, image) pair gets a top-2 margin of ~ b / 2 = 1 at |logit| ~ 3-5: 30-60 x the implementations' logit
+# differences.  The flip pattern gives every candidate its own count, a few of them equal (the argsort tie rule stays exercised).
+# The features come from the ORACLE (test infrastructure) — they only shape the head; every stored expectation is the REAL reference's.
+def _head_of(model, layout):
+    return model.classifier if layout == "hf" else model.head
+
+
+def _cls_features(model, layout, px):
+    """fp32 copy of what the classifier head receives (the CLS row behind the final LayerNorm) under the reference's autocast."""
+    from oracle import ref_cpu
+    got = {}
+    h = _head_of(model, layout).register_forward_pre_hook(lambda m, inp: got.__setitem__("f", inp[0].detach().float().clone()))
+    try:
+        with torch.no_grad(), torch.autocast("cpu", enabled=True):
+            ref_cpu._call(model, px)
+    finally:
+        h.remove()
+    return got["f"]
+
+
+def design_decisive_head(model, layout, px, flips, a=0.2, b=2.0):
+    """-> (rows f32 [2n, d], bias f32 [2n], report).  flips[c] = the images candidate c shall flip."""
+    import copy
+    from oracle import ref_cpu
+    depth = len(ref_cpu._blocks_of(model))
+    F0 = _cls_features(model, layout, px).double()
+    n, d = F0.shape
+    D = []
+    for c in range(depth):
+        m = copy.deepcopy(model)
+        ref_cpu.bypass_attention_(m, c)
+        D.append(_cls_features(m, layout, px).double() - F0)
+        del m
+    D = torch.stack(D)                                           # [depth, n, d]
+    mu = F0.mean(0)
+    dd = F0 - mu
+    rows = torch.zeros(2 * n, d, dtype=torch.float64); bias = torch.zeros(2 * n, dtype=torch.float64)
+    vnorm = []
+    cross = False      # "other images' bypass shifts project to zero too" (depth x (n - 1) more equations) was tried: |v| 1 -> 9, and the
+                       # implementations' feature differences grow with it (ViT-L/16: logit discrepancy 0.34, margins down to 0.02) — off
+    for i in range(n):
+        u = dd[i] / dd[i].norm()
+        rows[i] = a * u; bias[i] = -a * float(u @ mu)
+        A, t = [D[c, i] for c in range(depth)], [1.0 if i in flips[c] else 0.0 for c in range(depth)]
+        for j in range(n):
+            if j != i:
+                A.append(F0[j] - F0[i]); t.append(0.0)
+                if cross:
+                    for c in range(depth):
+                        A.append(D[c, j]); t.append(0.0)
+        v = torch.linalg.pinv(torch.stack(A)) @ torch.tensor(t, dtype=torch.float64)
+        vnorm.append(float(v.norm()))
+        rows[n + i] = rows[i] + b * v
+        bias[n + i] = bias[i] - b * float(v @ F0[i]) - b / 2
+    return rows.float(), bias.float(), {"v_norm_max": max(vnorm), "bypass_shift_min": float(D.norm(dim=2).min()),
+                                        "bypass_shift_max": float(D.norm(dim=2).max()), "cross_constraints": cross}
+
+
+def install_head(model, layout, rows, bias, classes):
+    head = _head_of(model, layout)
+    with torch.no_grad():
+        head.weight.zero_(); head.bias.fill_(-5.0)
+        head.weight[: rows.shape[0]].copy_(rows); head.bias[: bias.shape[0]].copy_(bias)
+    assert head.weight.shape[0] == classes
+
+
+def flip_pattern(depth, n):
+    """Candidate c flips k_c images: counts 0 .. ~n/3 in a fixed irregular order, some equal; images dealt with stride 5."""
+    ks = [(c * 7 + 3) % (n // 3 + 1) for c in range(depth)]
+    return [set(((c * 3 + m * 5) % n) for m in range(ks[c])) for c in range(depth)], ks
+
+
+def decisive_stage2_case(name, tag, n_per_batch, layout, targets=(0.25, 0.375, 0.5), with_stage1=False):
+    """Stage 2 at FULL depth against the REAL reference on a fixture where every (pass, image) pair is decided by a wide margin
+    (see the block comment above): the dense top-1, the depth-importance vector and the argsort selections can then be compared
+    EXACTLY.  Body weights and pixels as in vit_deep_case / vit_b16_case (regenerated from the seeds, checksummed); stored: the
+    designed head rows, labels (= the dense argmax under the reference's autocast = the image's own class), the reference's top-1,
+    att_imp and selections, the oracle's per-pair margins and the fp32-vs-bf16 oracle logit discrepancy.  `with_stage1`: also the
+    reference's bf16 stage-1 scores and masks + the oracle's fp32-chain scores (a geometry that has no stage-1 fixture yet)."""
+    import copy
+    import time
+    from oracle import ref_cpu
+    from ssp2vit.planner import plan_from_stats, stats_from_shapes
+    img, patch, dim, heads, inter, depth = VIT_CONFIGS[name]
+    t0 = time.time()
+    w = synthetic_weights(name, classes=1000, seed=0, std=0.02, eps=1e-6 if layout == "timm" else 1e-12, spread=4.0)
+    model = build_from_flat(w, layout).eval()
+    g = torch.Generator().manual_seed(1)
+    pxs = [torch.randn(n_per_batch, 3, img, img, generator=g) for _ in range(2)]
+    px = torch.cat(pxs)
+    n = px.shape[0]
+    flips, ks = flip_pattern(depth, n)
+    rows, bias, rep = design_decisive_head(model, layout, px, flips)
+    install_head(model, layout, rows, bias, 1000)
+    print(f"[golden] {tag}: head designed after {time.time() - t0:.0f} s: {rep}", flush=True)
+    # the oracle's view of every pass: label margin per (pass, image); pass 0 = dense
+    def margins(m):
+        lg = ref_cpu.logits_of(m, px).float()
+        lab = lg[torch.arange(n), torch.arange(n)]
+        oth = lg.clone(); oth[torch.arange(n), torch.arange(n)] = -1e9
+        return lab - oth.max(1).values, lg
+    mg0, lg0 = margins(model)
+    with torch.no_grad():
+        lg32 = ref_cpu._call(model, px).float()
+    disc = float((lg32 - lg0).abs().max())
+    mg = [mg0]
+    for c in range(depth):
+        m = copy.deepcopy(model); ref_cpu.bypass_attention_(m, c)
+        mg.append(margins(m)[0]); del m
+    mg = torch.stack(mg)                                          # [depth + 1, n]
+    min_abs = float(mg.abs().min())
+    print(f"[golden] {tag}: smallest |label margin| over {depth + 1} x {n} pairs = {min_abs:.3f}; fp32-vs-bf16 oracle logit discrepancy {disc:.4f}; "
+          f"max |logit| {float(lg0.abs().max()):.2f}", flush=True)
+    assert bool((mg[0] > 0).all()), "the dense model must take every image's own class"
+    assert min_abs >= 0.5 and min_abs >= 8 * disc, "fixture not decisive: adjust a / b"      # VERDICT r04 asked for 4 x the measured logit error
+    batches = [{"pixel_values": pxs[i], "labels": torch.arange(i * n_per_batch, (i + 1) * n_per_batch)} for i in range(2)]
+    rec = {"weights_checksum": np.float64(sum(float(v.double().sum()) for k, v in w.items() if isinstance(v, torch.Tensor) and not k.startswith("head_"))),
+           "pixels_checksum": np.float64(float(px.double().sum())), "n_per_batch": np.int64(n_per_batch), "layout": np.asarray(layout),
+           "head_rows": rows.numpy(), "head_bias": bias.numpy(), "rest_bias": np.float32(-5.0),
+           "oracle_margins": mg.numpy(), "oracle_fp32_vs_bf16_logit_disc": np.float64(disc), "designed_flips_per_candidate": np.asarray(ks, dtype=np.int64)}
+    for i, bt in enumerate(batches):
+        rec[f"labels.{i}"] = bt["labels"].numpy()
+    # ---- the REAL reference on this model
+    rec["top1"] = np.float64(ref_vp.evaluate_top1(model, batches, device="cpu"))
+    iface = ref_mc.Auto2SSPInterface(model, batches, device="cpu", importance_mode="copy", batch_limit=5)
+    rec["att_imp"] = quiet(iface._compute_att_depth_importance).numpy()
+    n_tok = (img // patch) ** 2 + 1
+    plans = [plan_from_stats(stats_from_shapes(dim, depth, inter, 1000, n_tok, patch), s_, 512) for s_ in targets]
+    rec["plan_K"] = np.asarray([p.blocks_to_prune for p in plans], dtype=np.int64)
+    rec["plan_t"] = np.asarray([p.per_block_neurons_to_prune for p in plans], dtype=np.int64)
+    for p in plans:
+        K = p.blocks_to_prune
+        rec[f"s2_selected_k{K}"] = np.asarray(sorted(int(i) for i in torch.argsort(torch.from_numpy(rec["att_imp"]))[:K]), dtype=np.int64)
+    assert rec["top1"] == 1.0
+    want = np.asarray([float(np.float32(max(0.0, 1.0 - (n - int((mg[c + 1] <= 0).sum())) / n))) for c in range(depth)])
+    assert np.allclose(rec["att_imp"], want, atol=1e-7), "the reference's impacts are the oracle margins' flips"
+    print(f"[golden] {tag}: reference top1={rec['top1']:.3f} impacts(images)={[int(round(float(v) * n)) for v in rec['att_imp']]} after {time.time() - t0:.0f} s", flush=True)
+    if with_stage1:
+        imps = ref_vp._compute_ffn_activation_importance(model, batches, device="cpu")
+        assert all(t.dtype == torch.bfloat16 for t in imps)
+        for i, t in enumerate(imps):
+            rec[f"s1_imp_bf16bits.{i}"] = bits(t)
+        for p in plans:
+            t = p.per_block_neurons_to_prune
+            r = quiet(ref_vp.prune_vit_mlp_width, copy.deepcopy(model), n_to_prune_per_block=[t] * depth, min_remaining=512,
+                      collect_masks=True, precomputed_importance=[x.to(torch.float32) for x in imps])
+            rec[f"mask.t{t}"] = np.packbits(np.asarray(r["ffn_prune_masks"], dtype=np.uint8), axis=1)
+            del r
+        o32 = ref_cpu.ffn_activation_importance(model, batches, chain="fp32")
+        for i, t in enumerate(o32):
+            rec[f"oracle_fp32.{i}"] = t.numpy()
+        ob = ref_cpu.ffn_activation_importance(model, batches)
+        assert all(torch.equal(x, y) for x, y in zip(ob, imps)), f"oracle != reference at {name} ({layout})"
+        print(f"[golden] {tag}: stage 1 done after {time.time() - t0:.0f} s", flush=True)
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **rec)
+    print(f"[golden] {tag}: written; {time.time() - t0:.0f} s", flush=True)
+
+
 def deep_logits_patch(name, tag, layout):
     """Adds the oracle's dense logits of EVERY batch to an existing full-depth fixture (round 4 stored batch 0 only at first)
     without re-running the reference's 25 / 33 passes: weights and pixels are regenerated from the seeds and checked against the
@@ -433,6 +603,15 @@ if __name__ == "__main__":
             vit_deep_case("vit_large_patch16_224", "vit_l16_2x12", 12, (0.25, 0.375, 0.5), layout="hf")
         if "--h14" in sys.argv:
             vit_deep_case("vit_huge_patch14_224", "vit_h14_2x8", 8, (0.25, 0.375, 0.5))
+        sys.exit(0)
+    if "--decisive" in sys.argv:
+        # decisive stage-2 fixtures (designed head): `--decisive b16hf l16 h14` or any subset
+        if "b16hf" in sys.argv:     # the reference CLI's default anatomy (HF google/vit-base-patch16-224: post-GELU hook, eps 1e-12) at the headline geometry
+            decisive_stage2_case("vit_base_patch16_224", "vit_b16_hf_2x32", 32, "hf", with_stage1=True)
+        if "l16" in sys.argv:
+            decisive_stage2_case("vit_large_patch16_224", "vit_l16_2x12_s2", 12, "hf")
+        if "h14" in sys.argv:
+            decisive_stage2_case("vit_huge_patch14_224", "vit_h14_2x8_s2", 8, "timm")
         sys.exit(0)
     if "--artifacts-only" in sys.argv:
         artifact_tool_cases()

@@ -1,0 +1,117 @@
+"""GPU parity of stage 2 at FULL depth on the DECISIVE fixtures (tests/golden/make_golden.py --decisive): the real
+reference's dense top-1, depth-importance vector and argsort selections on ViT-B/16 in the reference CLI's DEFAULT anatomy (old-HF
+layout: post-GELU hook, eps 1e-12 — auto_2ssp.py:1039, src/vit_pruning.py:126-131), ViT-L/16 (old-HF) and ViT-H/14 (timm), with a
+classifier head designed so that every (pass, image) pair is decided by a margin of >= 0.5 logits — more than 8 x the fp32-vs-bf16
+discrepancy of the CPU oracle itself.  Nothing here is a band: counts, impacts and selections must be EQUAL to the reference's.
+(The random-head fixtures of test_gpu_parity.py stay: they pin stage 1 and the logits; their stage-2 rule had to allow for near-ties.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, bf16_from_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(name, layout, z):
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights(name, classes=1000, seed=0, std=0.02, eps=1e-6 if layout == "timm" else 1e-12, spread=4.0)
+    body = sum(float(v.double().sum()) for k, v in w.items() if isinstance(v, torch.Tensor) and not k.startswith("head_"))
+    assert np.isclose(body, float(z["weights_checksum"]), rtol=1e-12), "regenerated body weights differ from the fixture's"
+    rows, bias = torch.from_numpy(z["head_rows"]), torch.from_numpy(z["head_bias"])
+    hw = torch.zeros_like(w["head_w"]); hb = torch.full_like(w["head_b"], float(z["rest_bias"]))
+    hw[: rows.shape[0]] = rows; hb[: bias.shape[0]] = bias
+    w["head_w"], w["head_b"] = hw, hb
+    return w
+
+
+@pytest.mark.parametrize("name,tag,layout", [("vit_base_patch16_224", "vit_b16_hf_2x32", "hf"),
+                                             ("vit_large_patch16_224", "vit_l16_2x12_s2", "hf"),
+                                             ("vit_huge_patch14_224", "vit_h14_2x8_s2", "timm")])
+def test_stage2_equals_the_reference_exactly_on_the_decisive_fixtures(name, tag, layout):
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import VIT_CONFIGS
+    z = dict(np.load(os.path.join(GOLDEN, f"{tag}.npz")))
+    img, patch, dim, heads, d_int, depth = VIT_CONFIGS[name]
+    nb = int(z["n_per_batch"]); n = 2 * nb
+    w = _weights(name, layout, z)
+    g = torch.Generator().manual_seed(1)
+    batches = [{"pixel_values": torch.randn(nb, 3, img, img, generator=g), "labels": torch.from_numpy(z[f"labels.{i}"])} for i in range(2)]
+    assert np.isclose(sum(float(b["pixel_values"].double().sum()) for b in batches), float(z["pixels_checksum"]), rtol=1e-9)
+    T = (img // patch) ** 2 + 1
+    eng = VitEngine(w, max_images=core.lm_capacity_images(T, depth, n, nb))
+    # the logits against the fixture's margins: how far from undecided is the worst pair on THIS implementation?
+    lg = eng.forward_logits(torch.cat([b["pixel_values"] for b in batches]).cuda()).cpu()
+    lab = lg[torch.arange(n), torch.arange(n)]
+    oth = lg.clone(); oth[torch.arange(n), torch.arange(n)] = -1e9
+    mg = (lab - oth.max(1).values).numpy()
+    err = float(np.abs(mg - z["oracle_margins"][0]).max())
+    print(f"\n[decisive {tag}] dense label margins: engine min {mg.min():.3f}, oracle min {z['oracle_margins'][0].min():.3f}; max |margin difference| {err:.4f}; "
+          f"smallest |margin| of all {depth + 1} x {n} pairs {np.abs(z['oracle_margins']).min():.3f} (oracle fp32-vs-bf16 logit discrepancy "
+          f"{float(z['oracle_fp32_vs_bf16_logit_disc']):.4f})")
+    assert 4 * err <= float(np.abs(z["oracle_margins"]).min()), "the engine's logit error is not small against the fixture's margins"
+    ref_imp = torch.from_numpy(z["att_imp"])
+    for mode in ("two", "one"):
+        if mode == "two":
+            base, cand, total = core.depth_search_counts(eng, batches, depth, batch_limit=5, chunk_images=n)
+        else:                              # the one-pass prune: the same integers from the hooked baseline
+            site = "post_gelu" if layout == "hf" else "pre_gelu"
+            _, (base, cand, total) = core.prune_pass(eng, batches, [d_int] * depth, site, depth, score_limit=5, search_limit=5, eval_chunk_images=n)
+        assert total == n and base == round(float(z["top1"]) * n) == n, (mode, base, total)
+        att = torch.tensor(core.impacts_from_counts(base, cand, total), dtype=torch.float32)
+        print(f"[decisive {tag}] {mode}-pass impacts (images): engine {[n - c for c in cand]}  reference {[int(round(float(v) * n)) for v in ref_imp]}")
+        assert torch.equal(att, ref_imp), (mode, att.tolist(), ref_imp.tolist())        # the float32 tensor the reference's interface returns, bit for bit
+        for K in z["plan_K"].tolist():
+            sel = sorted(int(i) for i in torch.argsort(att)[:K])                        # auto_2ssp.py:857
+            assert sel == z[f"s2_selected_k{K}"].tolist(), (mode, K, sel)
+    eng.close()
+
+
+def test_vit_b16_in_the_reference_clis_default_anatomy_stage1_vs_reference_golden():
+    """Stage 1 at the headline geometry in the anatomy the reference's CLI loads by default (HF google/vit-base-patch16-224:
+    hook on `intermediate` = POST-GELU, LayerNorm eps 1e-12 — src/vit_pruning.py:126-131) against the real reference's bf16 scores and
+    masks (tests/golden/vit_b16_hf_2x32.npz).  bf16_ref chain: <= 2 ulp (two accumulated batches), >= 90 % identical; fp32 chain against
+    the oracle's fp32-chain scores: the post-GELU site's error is what mask_parity's band for that site must cover — printed per block,
+    bound = the product's MASK_PARITY_EPS_POST_GELU / 2; masks equal to the oracle-score masks in every block the product's report
+    calls `guaranteed`."""
+    from oracle import ref_cpu
+    from ssp2vit import core
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.mask_parity import MASK_PARITY_EPS_POST_GELU, mask_parity_report
+    z = dict(np.load(os.path.join(GOLDEN, "vit_b16_hf_2x32.npz")))
+    w = _weights("vit_base_patch16_224", "hf", z)
+    g = torch.Generator().manual_seed(1)
+    batches = [{"pixel_values": torch.randn(32, 3, 224, 224, generator=g)} for _ in range(2)]
+    eng = VitEngine(w, max_images=64)
+    d_ints = [3072] * 12
+    got_b = core.stage1_scores(eng, batches, d_ints, "post_gelu", score_chain="bf16_ref")
+    got_f = core.stage1_scores(eng, batches, d_ints, "post_gelu", score_chain="fp32")
+    ref_f = [torch.from_numpy(z[f"oracle_fp32.{l}"]) for l in range(12)]
+    worst = 0.0
+    print()
+    for l in range(12):
+        refb = bf16_from_bits(z[f"s1_imp_bf16bits.{l}"])
+        ulp = (got_b[l].view(torch.int16).int() - refb.view(torch.int16).int()).abs()
+        exact = float((ulp == 0).float().mean())
+        rel = float(((got_f[l] - ref_f[l]).abs() / ref_f[l].abs().clamp_min(1e-6)).max())
+        worst = max(worst, rel)
+        print(f"[b16-hf] block {l:2d}: bf16 chain max {int(ulp.max())} ulp, {100 * exact:.1f} % identical | fp32 chain rel err max {rel:.2e}")
+        assert int(ulp.max()) <= 2 and exact >= 0.9, (l, int(ulp.max()), exact)
+    print(f"[b16-hf] worst fp32-chain relative error {worst:.2e} (mask_parity's band for this site: eps = {MASK_PARITY_EPS_POST_GELU})")
+    assert worst <= MASK_PARITY_EPS_POST_GELU / 2
+    for t in z["plan_t"].tolist():
+        g_masks, _ = ref_cpu.width_prune_selection(got_f, [t] * 12, min_remaining=512)
+        o_masks, _ = ref_cpu.width_prune_selection(ref_f, [t] * 12, min_remaining=512)
+        rep = mask_parity_report(got_f, [t] * 12, min_remaining=512, site="post_gelu")
+        bits = 0
+        for l in range(12):
+            d = sum(a != b for a, b in zip(g_masks[l], o_masks[l]))
+            bits += d
+            if rep["blocks"][l]["guaranteed"]:
+                assert d == 0, (t, l)
+        ref_bits = int((np.asarray(g_masks, dtype=np.uint8) != np.unpackbits(z[f"mask.t{t}"], axis=1)[:, :3072]).sum())
+        print(f"[b16-hf] t={t}: {rep['blocks_guaranteed']} of 12 blocks guaranteed, {bits} bits differ from the oracle-score masks, {ref_bits} from the reference's bf16-score masks")
+    eng.close()

@@ -189,3 +189,50 @@ def test_full_depth_large_geometries_pin_the_oracle(name, tag, layout):
         assert ref_cpu.evaluate_top1(model, batches) == float(z["top1"])
     finally:
         torch.set_num_threads(old_threads)
+
+
+def _decisive_model(name, layout, z):
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights(name, classes=1000, seed=0, std=0.02, eps=1e-6 if layout == "timm" else 1e-12, spread=4.0)
+    rows, bias = torch.from_numpy(z["head_rows"]), torch.from_numpy(z["head_bias"])
+    hw = torch.zeros_like(w["head_w"]); hb = torch.full_like(w["head_b"], float(z["rest_bias"]))
+    hw[: rows.shape[0]] = rows; hb[: bias.shape[0]] = bias
+    w["head_w"], w["head_b"] = hw, hb
+    return build_from_flat(w, layout)
+
+
+@pytest.mark.timeout(600)
+def test_vit_b16_hf_decisive_fixture_pins_the_oracle():
+    """tests/golden/vit_b16_hf_2x32.npz (make_golden.py --decisive b16hf): the reference CLI's DEFAULT anatomy at the headline geometry
+    (old-HF layout, post-GELU hook, eps 1e-12) with the designed classifier head — the oracle reproduces the REAL reference's bf16
+    stage-1 scores, its masks, its dense top-1 and its depth-importance vector bit for bit, and the stored margins say every
+    (pass, image) pair is decided by >= 0.5 logits."""
+    z = dict(np.load(f"{GOLDEN}/vit_b16_hf_2x32.npz"))
+    model = _decisive_model("vit_base_patch16_224", "hf", z)
+    g = torch.Generator().manual_seed(1)
+    batches = [{"pixel_values": torch.randn(32, 3, 224, 224, generator=g), "labels": torch.from_numpy(z[f"labels.{i}"])} for i in range(2)]
+    imps = ref_cpu.ffn_activation_importance(model, batches)
+    for l, t in enumerate(imps):
+        assert torch.equal(t.view(torch.int16), bf16_from_bits(z[f"s1_imp_bf16bits.{l}"]).view(torch.int16)), l
+    for t in z["plan_t"].tolist():
+        masks, _ = ref_cpu.width_prune_selection([x.float() for x in imps], [t] * 12, min_remaining=512)
+        assert np.array_equal(np.asarray(masks, dtype=np.uint8), np.unpackbits(z[f"mask.t{t}"], axis=1)[:, :3072]), t
+    assert ref_cpu.evaluate_top1(model, batches) == float(z["top1"]) == 1.0
+    att = ref_cpu.att_depth_importance(model, batches, 5)
+    assert torch.equal(att, torch.from_numpy(z["att_imp"]))
+    assert float(np.abs(z["oracle_margins"]).min()) >= 0.5 >= 8 * float(z["oracle_fp32_vs_bf16_logit_disc"])
+
+
+@pytest.mark.parametrize("tag,depth,n", [("vit_b16_hf_2x32", 12, 64), ("vit_l16_2x12_s2", 24, 24), ("vit_h14_2x8_s2", 32, 16)])
+def test_decisive_fixtures_are_decisive_and_self_consistent(tag, depth, n):
+    """Data checks of the decisive stage-2 fixtures (no forward here; make_golden.py asserted oracle == reference when it wrote them, and
+    the B/16 one is re-run above): every pair's margin is >= 0.5 and >= 8 x the oracle's own fp32-vs-bf16 logit discrepancy, the
+    reference's impacts are exactly the flips those margins imply, candidates differ, and the selections are torch.argsort's."""
+    z = dict(np.load(f"{GOLDEN}/{tag}.npz"))
+    mg = z["oracle_margins"]
+    assert mg.shape == (depth + 1, n) and (mg[0] > 0).all()
+    assert float(np.abs(mg).min()) >= 0.5 and float(np.abs(mg).min()) >= 8 * float(z["oracle_fp32_vs_bf16_logit_disc"])
+    flips = (mg[1:] <= 0).sum(1)
+    assert np.array_equal(np.round(z["att_imp"] * n).astype(int), flips) and len(set(flips.tolist())) >= 5
+    for K in z["plan_K"].tolist():
+        assert sorted(int(i) for i in torch.argsort(torch.from_numpy(z["att_imp"]))[:K]) == z[f"s2_selected_k{K}"].tolist()
