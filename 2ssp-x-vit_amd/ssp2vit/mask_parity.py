@@ -16,10 +16,13 @@ import torch
 MASK_PARITY_EPS = float(os.environ.get("SSP2_MASK_PARITY_EPS", "1e-3"))
 # The POST-GELU hook site (old-HF / HF >= 5 anatomy, reference :130) is noisier than the pre-GELU one (timm, :135): a weak neuron's
 # score is a norm of GELU-tail values, whose relative sensitivity to a one-ulp bf16 flip of the pre-activation is several times
-# that of the pre-activation itself.  Measured on MI355X against the CPU restatement, largest per-element relative error of the
-# fp32 chain (profiles/r04_c_site_diag.txt): pre-GELU 2.7e-4 (ViT-B/16, 64 samples) .. 6.6e-4 (ViT-L/16, 24 samples); post-GELU
-# 1.9e-3 .. 4.7e-3 on the same weights and images.  Hence twice 5e-3 for that site.
-MASK_PARITY_EPS_POST_GELU = float(os.environ.get("SSP2_MASK_PARITY_EPS_POST_GELU", "1e-2"))
+# that of the pre-activation itself.  Its band is EMPIRICAL and the report says so (`basis`): largest per-element relative error of the
+# fp32 chain against the CPU restatement over every (model, images) sample measured on MI355X so far — ViT-B/16 HF 64 samples 1.6e-3 /
+# 1.9e-3 (two weight sets), 24 samples 2.4e-3; ViT-L/16 HF 24 samples 4.3e-3 .. 4.7e-3 (two seeds; the fewer samples, the less the
+# outliers average out) — pre-GELU on the same weights 2.7e-4 .. 6.6e-4 (profiles/r04_c_site_diag.txt, r05_e_decisive_stage2.log).
+# Error bound = the largest of them + 25 % = 5.9e-3; the band is twice that.  (Round 4 used 1e-2 = 2.1 x the worst sample)
+POST_GELU_ERROR_BOUND = 5.9e-3
+MASK_PARITY_EPS_POST_GELU = float(os.environ.get("SSP2_MASK_PARITY_EPS_POST_GELU", str(2 * POST_GELU_ERROR_BOUND)))
 
 
 def eps_for_site(site: Optional[str]) -> float:
@@ -58,6 +61,8 @@ def mask_parity_report(scores: Sequence[torch.Tensor], n_prune_per_block: Sequen
         blocks.append({"block": b, "pruned": drop, "cut_margin": margin, "tie_band": band, "exact_ties": ties,
                        "guaranteed": band == 0})
     margins = [x["cut_margin"] for x in blocks if x["cut_margin"] is not None]
-    return {"eps": eps, "score_site": site or "pre_gelu", "blocks": blocks, "blocks_guaranteed": sum(1 for x in blocks if x["guaranteed"]),
+    basis = ("empirical: twice (the largest fp32-chain score error measured on MI355X against the CPU restatement + 25 %); not a derived bound"
+             if site == "post_gelu" else "twice the 5e-4 bound on the fp32-chain score error (measured <= 4.6e-4 on MI355X)")
+    return {"eps": eps, "score_site": site or "pre_gelu", "basis": basis, "blocks": blocks, "blocks_guaranteed": sum(1 for x in blocks if x["guaranteed"]),
             "blocks_total": len(blocks), "min_margin": min(margins) if margins else None,
             "rule": "mask == CPU-reference mask from fp32 scores wherever tie_band == 0 (cut_margin > eps = 2 x score error bound)"}

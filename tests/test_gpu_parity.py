@@ -943,13 +943,14 @@ def test_full_depth_large_geometries_vs_reference_golden(gpu, name, tag, layout)
         the dividend lands in the lower two thirds of the quotient's binade as 2 x 4/3 = 2.67 ulp and rounds to 3 (the first run
         on hardware, written against "<= 2", showed exactly that: one element of 98 304 at 3 ulp, in block 1)
       * fp32 chain vs the oracle's fp32-chain scores: per element rel <= 2e-3 at the PRE-GELU site (the ViT-B/16 rule; ViT-H/14
-        measures 8.2e-4) and <= 1e-2 at the POST-GELU site; <= 3e-4 on average per block at either.  The post-GELU bound was set AFTER
+        measures 8.2e-4) and <= 5.9e-3 at the POST-GELU site (round 5: the largest error ever measured, 4.7e-3 on this fixture, + 25 %;
+        round 4 had 1e-2); <= 3e-4 on average per block at either.  The post-GELU bound was set AFTER
         the first runs on hardware and says so: written against 2e-3, ViT-L/16 (old-HF anatomy) measured 4.7e-3 on its worst element of
         98 304 (block 21; median 1.3e-4, p99 1.2e-3, zero mean).  scripts/deep_site_diag.py then ran both anatomies on the SAME weights
         and images against the oracle (profiles/r04_c_site_diag.txt): pre-GELU 2.7e-4 .. 6.6e-4, post-GELU 1.9e-3 .. 4.3e-3 — the
         site, not the geometry or the kernel (both GEMM routings give the same bits): a weak neuron's post-GELU score is a norm of
         GELU-tail values, several times as sensitive to a one-ulp bf16 flip of the pre-activation as the pre-activation itself.  The
-        product's mask-parity report uses the same site-dependent band (ssp2vit/mask_parity.py: eps 1e-2 for that site).
+        product's mask-parity report uses twice that bound as its (empirical, labelled so) band for the site (ssp2vit/mask_parity.py).
       * masks at the planner's t for 25 / 37.5 / 50 %: identical to the oracle-score masks in EVERY block the product's own report
         calls `guaranteed`; <= one differing bit pair per block on average overall (2 * depth bits)
       * dense logits of batch 0 vs the oracle's: |err| <= 2^-6 * max|logit| (both routings), the two routings bit-identical
@@ -986,7 +987,8 @@ def test_full_depth_large_geometries_vs_reference_golden(gpu, name, tag, layout)
     ref_f = [torch.from_numpy(z[f"oracle_fp32.{l}"]) for l in range(depth)]
     print()
     worst_ulp, worst_exact, worst_rel, worst_mean = 0, 1.0, 0.0, 0.0
-    rel_bound = 2e-3 if site == "pre_gelu" else 1e-2
+    from ssp2vit.mask_parity import POST_GELU_ERROR_BOUND
+    rel_bound = 2e-3 if site == "pre_gelu" else POST_GELU_ERROR_BOUND          # post-GELU: the largest error measured so far (4.7e-3, this fixture) + 25 %
     for l in range(depth):
         refb = bf16_from_bits(z[f"s1_imp_bf16bits.{l}"])
         ulp = (got_b[l].view(torch.int16).int() - refb.view(torch.int16).int()).abs()
