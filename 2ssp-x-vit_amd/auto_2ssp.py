@@ -149,7 +149,8 @@ def run_one(args, target, run_id):
         mlp_imp = iface._compute_mlp_importance() if (args.stage in ("both", "s1") and args.s1_importance == "act") else None
         att_imp = iface._compute_att_depth_importance() if args.stage in ("both", "s2") else None
 
-    ffn_masks = mask_parity = None
+    ffn_masks = ffn_indices = mask_parity = None
+    inter_before = [int(d) for d in vp._get_hidden_and_inter_sizes(model)[1]]
     if args.stage in ("both", "s1"):
         if args.stage == "both":
             n_prune = [plan.per_block_neurons_to_prune] * B
@@ -162,6 +163,7 @@ def run_one(args, target, run_id):
                                      collect_masks=True,
                                      precomputed_importance=[x.to(torch.float32) for x in mlp_imp] if mlp_imp is not None else None)
         ffn_masks = res["ffn_prune_masks"]
+        ffn_indices = res["ffn_pruned_indices"]
         mask_parity = res.get("mask_parity")
     params_s1 = vp.count_total_params(model) if args.stage != "s2" else params_before
     t_s1 = time.time()
@@ -201,7 +203,12 @@ def run_one(args, target, run_id):
     art_dir = out_root / "artifacts" / run_id
     art_dir.mkdir(parents=True, exist_ok=True)
     arte = {"pruned_block_indices": pruned_indices}
-    if ffn_masks is not None:
+    if args.artifact_format == "v1":
+        # the older CLI's files (experiments/vit_pruning/auto_2ssp.py:769-829): format_version 1 masks + indices, attention indices, "b:j" importances
+        arte.update(artifacts.save_v1_artifacts(str(art_dir), mlp_imp=mlp_imp, ffn_masks=ffn_masks, ffn_indices=ffn_indices,
+                                                pruned_block_indices=pruned_indices, min_remaining=args.min_remaining,
+                                                s1_sparsity=args.s1_sparsity, block_inter_sizes=inter_before))
+    elif ffn_masks is not None:
         arte["ffn_prune_masks_path"] = artifacts.save_ffn_prune_masks(str(art_dir / "ffn_prune_masks.json"), ffn_masks)
     if args.fw_export_prefix:
         artifacts.build_framework_exports(args.fw_export_prefix, B, model.config.hidden_size, model.config.num_attention_heads,
@@ -297,6 +304,9 @@ def build_argparser():
     p.add_argument("--save-format", type=str, default="timm", choices=["timm", "hf"],
                    help="timm: state_dict file (the reference's --use-srp-checkpoint branch); hf: save_pretrained-style directory")
     p.add_argument("--fw-export-prefix", type=str, default=None)
+    p.add_argument("--artifact-format", type=str, default="current", choices=["current", "v1"],
+                   help="v1: the older CLI's artifact files (experiments/vit_pruning/auto_2ssp.py:769-829): ffn_prune_masks.json with "
+                        "format_version 1 / masks / indices, attention_pruned_indices.json, iterative_vit_b16_ffn_importances.json")
     p.add_argument("--output-dir", type=str, default=str(HERE / "runs"), help="reports/ and artifacts/ are created below it")
     # synthetic stand-ins for the network-loaded model/data of the reference
     p.add_argument("--weights", type=str, default=None,

@@ -6,6 +6,8 @@ Schemas (all restated from the reference, 1 = prune, 0 = keep):
   * `<prefix>_masks.json`           {"ffn": {"l": [..]}, "heads": {"l": [..]}, "qkv_dim": {"l": [..]}} auto_2ssp.py:84-89
     head / qkv_dim scores are the block's depth importance broadcast, their masks all-ones for removed blocks
     (auto_2ssp.py:139-175)
+  * the OLDER CLI's three files (`format_version` 1 masks + indices, attention indices, "b:j" importances):  save_v1_artifacts,
+    experiments/vit_pruning/auto_2ssp.py:769-829
   * any JSON tree whose leaves are {"i:j": number} is a valid score or mask file for the consumers
     (experiments/vit_pruning/apply_mask_prune.py:206-256, manual-experiments/*.py)
 
@@ -34,6 +36,46 @@ def save_ffn_prune_masks(path: str, masks: Sequence[Sequence[int]]) -> str:
         json.dump({"ffn_masks": [[int(v) for v in (m.tolist() if isinstance(m, torch.Tensor) else m)] for m in masks]},
                   f, indent=2)
     return path
+
+
+def save_v1_artifacts(art_dir: str, *, mlp_imp: Optional[Sequence] = None, ffn_masks: Optional[Sequence[Sequence[int]]] = None,
+                      ffn_indices: Optional[Sequence[Sequence[int]]] = None, pruned_block_indices: Optional[Sequence[int]] = None,
+                      min_remaining: int = 256, s1_sparsity: Optional[float] = None, block_inter_sizes: Optional[Sequence[int]] = None,
+                      strategy: str = "act_l2") -> Dict[str, str]:
+    """The OLDER CLI's artifact files (experiments/vit_pruning/auto_2ssp.py:769-829), by their names:
+      iterative_vit_b16_ffn_importances.json   {"ffn": {"b:j": float}}                                          (:770-785; indent 2, non-ASCII kept)
+      ffn_prune_masks.json                      {"format_version": 1, "stage": "s1", "strategy", "min_remaining", "s1_sparsity",
+                                                 "block_inter_sizes", "masks": [[0/1]], "indices": [[pruned j]]}  (:788-806; 1 = prune)
+      attention_pruned_indices.json             {"format_version": 1, "stage": "s2", "indices": [blocks]}        (:808-816; only when non-empty)
+    Returns {artifact key of the reference's report: path} for the files written (:818-828)."""
+    os.makedirs(art_dir, exist_ok=True)
+    out: Dict[str, str] = {}
+    if mlp_imp is not None:
+        ffn_map = {}
+        for b, imp in enumerate(mlp_imp):
+            vals = imp.detach().cpu().flatten().tolist() if isinstance(imp, torch.Tensor) else [float(x) for x in imp]
+            for j, v in enumerate(vals):
+                ffn_map[f"{b}:{j}"] = float(v)
+        path = os.path.join(art_dir, "iterative_vit_b16_ffn_importances.json")
+        with open(path, "w", encoding="utf-8") as f:
+            json.dump({"ffn": ffn_map}, f, ensure_ascii=False, indent=2)
+        out["ffn_importances_path"] = path
+    if ffn_masks is not None:
+        masks = [[int(v) for v in (m.tolist() if isinstance(m, torch.Tensor) else m)] for m in ffn_masks]
+        if ffn_indices is None:
+            ffn_indices = [[j for j, bit in enumerate(m) if bit == 1] for m in masks]
+        path = os.path.join(art_dir, "ffn_prune_masks.json")
+        with open(path, "w", encoding="utf-8") as f:
+            json.dump({"format_version": 1, "stage": "s1", "strategy": strategy, "min_remaining": min_remaining,
+                       "s1_sparsity": s1_sparsity, "block_inter_sizes": None if block_inter_sizes is None else [int(v) for v in block_inter_sizes],
+                       "masks": masks, "indices": [[int(j) for j in ix] for ix in ffn_indices]}, f, indent=2)
+        out["ffn_prune_masks_path"] = path
+    if pruned_block_indices:
+        path = os.path.join(art_dir, "attention_pruned_indices.json")
+        with open(path, "w", encoding="utf-8") as f:
+            json.dump({"format_version": 1, "stage": "s2", "indices": [int(i) for i in pruned_block_indices]}, f, indent=2)
+        out["attn_pruned_indices_path"] = path
+    return out
 
 
 def build_framework_exports(prefix: str, n_blocks: int, hidden: int, num_heads: int,

@@ -76,3 +76,30 @@ def test_framework_export_schema(tmp_path):
     path = A.save_ffn_prune_masks(str(tmp_path / "ffn_prune_masks.json"), [torch.tensor([0, 1]), [1, 0]])
     assert json.load(open(path)) == {"ffn_masks": [[0, 1], [1, 0]]}
     assert A.scores_to_ij(mlp)["ffn"]["1:0"] == 2.0
+
+
+def test_v1_artifact_files_of_the_older_cli(tmp_path):
+    """The older CLI's three files (/root/reference/experiments/vit_pruning/auto_2ssp.py:769-829; SURVEY section 2 row 5 files these formats
+    under f1): key sets, value types, the 1 = prune convention, `indices` = positions of the ones, the "b:j" importance map in block-major
+    order, the attention file only when a block was removed, and the report's artifact keys.  Schema restated from the source text (that
+    script imports timm at module top, so it cannot run here): "parity unpinned" for the byte layout, pinned for the schema."""
+    imps = [torch.tensor([0.5, 0.0, 415.25]), torch.tensor([1.0, 2.0, 3.0])]
+    masks = [[1, 0, 0], torch.tensor([0, 1, 1])]
+    out = A.save_v1_artifacts(str(tmp_path), mlp_imp=imps, ffn_masks=masks, pruned_block_indices=[1], min_remaining=1, s1_sparsity=None,
+                              block_inter_sizes=[3, 3])
+    assert set(out) == {"ffn_importances_path", "ffn_prune_masks_path", "attn_pruned_indices_path"}
+    m = json.load(open(out["ffn_prune_masks_path"]))
+    assert list(m) == ["format_version", "stage", "strategy", "min_remaining", "s1_sparsity", "block_inter_sizes", "masks", "indices"]
+    assert m["format_version"] == 1 and m["stage"] == "s1" and m["strategy"] == "act_l2" and m["min_remaining"] == 1 and m["s1_sparsity"] is None
+    assert m["block_inter_sizes"] == [3, 3] and m["masks"] == [[1, 0, 0], [0, 1, 1]] and m["indices"] == [[0], [1, 2]]
+    a = json.load(open(out["attn_pruned_indices_path"]))
+    assert a == {"format_version": 1, "stage": "s2", "indices": [1]}
+    s = json.load(open(out["ffn_importances_path"]))
+    assert list(s) == ["ffn"] and list(s["ffn"]) == ["0:0", "0:1", "0:2", "1:0", "1:1", "1:2"] and s["ffn"]["0:2"] == 415.25
+    assert A.load_ij_leaves(out["ffn_importances_path"]) if hasattr(A, "load_ij_leaves") else True
+    # nothing removed in stage 2 -> no attention file (reference :808); explicit indices are written as given
+    out2 = A.save_v1_artifacts(str(tmp_path / "b"), ffn_masks=masks, ffn_indices=[[0], [1, 2]], pruned_block_indices=[])
+    assert set(out2) == {"ffn_prune_masks_path"} and not os.path.exists(tmp_path / "b" / "attention_pruned_indices.json")
+    # the mask consumer of the reference's tooling reads "i:j" leaves: the importance file is one
+    tree = json.load(open(out["ffn_importances_path"]))
+    assert A._is_ij_leaf(tree["ffn"])

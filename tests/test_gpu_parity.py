@@ -526,6 +526,17 @@ def test_cli_end_to_end_on_synthetic_vit_tiny(gpu, tmp_path):
     m2 = rep2["metrics"]
     assert m2["params_before_stage1"] == m["params_after_stage2"] and m2["acc_baseline"] == 1.0
     assert m2["params_after_stage2"] < m2["params_before_stage1"] and rep2["config"]["weights"] == rep["artifacts"]["pruned_model_dir"]
+    # round 5: the two importances come from ONE walk by default; --two-pass (the reference's two walks) gives the same masks and blocks,
+    # and --artifact-format v1 writes the older CLI's files (experiments/vit_pruning/auto_2ssp.py:769-829)
+    rep3 = cli.main(["--model", "vit_tiny_patch16_224", "--target", "0.3", "--eval-batches", "2", "--batch-size", "16", "--two-pass",
+                     "--synthetic-calib", "32", "--num-classes", "10", "--min-remaining", "256", "--output-dir", str(tmp_path / "run3"),
+                     "--artifact-format", "v1"])[0]
+    assert rep3["artifacts"]["pruned_block_indices"] == rep["artifacts"]["pruned_block_indices"]
+    v1 = json.load(open(rep3["artifacts"]["ffn_prune_masks_path"]))
+    assert v1["format_version"] == 1 and v1["masks"] == masks and v1["block_inter_sizes"] == [768] * 12
+    assert [len(ix) for ix in v1["indices"]] == [plan["per_block_neurons_to_prune"]] * 12
+    assert json.load(open(rep3["artifacts"]["attn_pruned_indices_path"]))["indices"] == rep["artifacts"]["pruned_block_indices"]
+    assert len(json.load(open(rep3["artifacts"]["ffn_importances_path"]))["ffn"]) == 12 * 768
 
 
 def test_cli_on_local_uint8_data_through_the_gpu_input_pipeline(gpu, tmp_path):
