@@ -255,6 +255,9 @@ static int launch_gemm256(ssp2_engine* e, GemmArgs g, int klass) {
 // Conditions when switched on: the launch goes to the 256 x 256 kernel, dim = 3, 4 or 5 column tiles, at least two K-tiles per
 // tile (the tile stream), and the XCC_ID probe at create saw nothing but ids 0..7.  Returns dim / 256 or 0.
 static int ln_fusable(const ssp2_engine* e, int M, int K, bool f8) {
+#ifndef SSP2_LAB
+  return 0;               // product build: the fused form is not instantiated (lab build: lib/libssp2vit_lab.so)
+#endif
   const int D = e->d.dim;
   const int on = e->opt[SSP2_OPT_LN_FUSION];
   if (!on || !e->xcc_ok || M < big_tile_min_rows(e) || D % 256 || D / 256 < 3 || D / 256 > 5 || !e->opt[SSP2_OPT_BIG_TILES]) return 0;
@@ -269,12 +272,16 @@ static int ln_fusable(const ssp2_engine* e, int M, int K, bool f8) {
 }
 template <bool F8>
 static int launch_resid_ln(ssp2_engine* e, const GemmArgs& g, int lnv, int klass) {
+#ifdef SSP2_LAB
   switch (lnv) {
     case 3: return launch_gemm256<EPI_RESID, 3, F8>(e, g, klass);
     case 4: return launch_gemm256<EPI_RESID, 4, F8>(e, g, klass);
     case 5: return launch_gemm256<EPI_RESID, 5, F8>(e, g, klass);
     default: return fail(SSP2_EINVAL, "fused LayerNorm: dim / 256 = %d unsupported", lnv);
   }
+#else
+  return fail(SSP2_ESTATE, "fused LayerNorm (dim / 256 = %d) exists in the lab build only", lnv);
+#endif
 }
 
 template <int EPI, int SCORE = 0>
@@ -284,9 +291,11 @@ static int launch_gemm(ssp2_engine* e, GemmArgs g, int klass) {
   if (g.K % GEMM_BK) return fail(SSP2_EINVAL, "GEMM K=%d not a multiple of %d", g.K, GEMM_BK);
   if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID || EPI == EPI_FC1) {
     if (g.M >= big_tile_min_rows(e) && !(EPI == EPI_FC1 && (g.out2 || !e->opt[SSP2_OPT_FC1_BIG_TILES])) && e->opt[SSP2_OPT_BIG_TILES]) {
+#ifdef SSP2_LAB
       if constexpr (EPI == EPI_RESID && SCORE == 0) {      // the deferred residual (same bits): full column tiles, a main loop long enough to ride on
         if (e->opt[SSP2_OPT_DEFER_RESID] && e->dg_scratch && g.N % 256 == 0 && g.K / 64 >= 4) return launch_gemm256<EPI_RESID, 1>(e, g, klass);
       }
+#endif
       return launch_gemm256<EPI, SCORE>(e, g, klass);
     }
   }
@@ -455,16 +464,28 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; };
     e->opt[SSP2_OPT_ZIGZAG] = env_int("SSP2_ZIGZAG", 1);
     e->opt[SSP2_OPT_ATTN_PERSIST] = env_int("SSP2_ATTN_PERSIST", 1);
+#ifdef SSP2_LAB
     e->opt[SSP2_OPT_LN_FUSION] = env_int("SSP2_LN_FUSION", 0);
+#else
+    e->opt[SSP2_OPT_LN_FUSION] = 0;
+#endif
     e->opt[SSP2_OPT_BIG_TILES] = getenv("SSP2_NO_BIG_TILES") ? 0 : 1;
     e->opt[SSP2_OPT_FC1_BIG_TILES] = getenv("SSP2_FC1_SMALL_TILES") ? 0 : 1;
+#ifdef SSP2_LAB
     e->opt[SSP2_OPT_GROUP256] = env_int("SSP2_GROUP256", 0);
+#else
+    e->opt[SSP2_OPT_GROUP256] = 0;
+#endif
     e->opt[SSP2_OPT_PATCH_LDS] = env_int("SSP2_PATCH_LDS", 1);
     e->opt[SSP2_OPT_ATTN_STAGGER] = env_int("SSP2_ATTN_STAGGER", 0);
     e->opt[SSP2_OPT_FP8_PROJ] = env_int("SSP2_FP8_PROJ", 1);
     e->opt[SSP2_OPT_BIG_TILE_MIN_ROWS] = std::max(256, env_int("SSP2_BIG_TILE_MIN_ROWS", kBigTileMinRowsDefault));
     e->opt[SSP2_OPT_NT_STORES] = env_int("SSP2_NT_STORES", 1);
+#ifdef SSP2_LAB
     e->opt[SSP2_OPT_DEFER_RESID] = env_int("SSP2_DEFER_RESID", 0);
+#else
+    e->opt[SSP2_OPT_DEFER_RESID] = 0;
+#endif
   }
   e->d_int.assign(d.d_int, d.d_int + d.depth);
   e->d.d_int = e->d_int.data();
@@ -524,7 +545,9 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
   TRY(dalloc(e, &e->act_cls, (size_t)d.max_images * e->ld_int_max, true));
   TRY(dalloc(e, &e->logits, (size_t)d.max_images * d.classes, true));
   TRY(dalloc(e, &e->ln_sync, (size_t)16 + (M + 255) / 256 + 1, true));
-  TRY(dalloc(e, &e->dg_scratch, (size_t)std::max(e->n_cu, 1) * 32768, true));      // 128 KiB per workgroup of the persistent GEMM
+#ifdef SSP2_LAB
+  TRY(dalloc(e, &e->dg_scratch, (size_t)std::max(e->n_cu, 1) * 32768, true));      // 128 KiB per workgroup of the persistent GEMM (deferred residual, lab build)
+#endif
 #undef TRY
   {   // the fused LayerNorm trusts the hardware's XCC_ID to name the L2 a workgroup sits behind: look at what it reports once
     unsigned int* ids = nullptr;
@@ -613,6 +636,11 @@ int ssp2_set_option(ssp2_handle e, int option, int value) {
   if (option == SSP2_OPT_LN_FUSION && (value < 0 || value > 2)) return fail(SSP2_EINVAL, "SSP2_OPT_LN_FUSION takes 0, 1 or 2");
   if (option == SSP2_OPT_GROUP256 && value < 0) return fail(SSP2_EINVAL, "SSP2_OPT_GROUP256 takes 100 * GM + GN >= 0");
   if (option == SSP2_OPT_BIG_TILE_MIN_ROWS && value < 256) return fail(SSP2_EINVAL, "SSP2_OPT_BIG_TILE_MIN_ROWS takes >= 256 rows");
+#ifndef SSP2_LAB
+  if ((option == SSP2_OPT_LN_FUSION || option == SSP2_OPT_DEFER_RESID || option == SSP2_OPT_GROUP256) && value != 0)
+    return fail(SSP2_ESTATE, "option %d (LayerNorm fusion / deferred residual / column-group tile order) exists in the lab build only: "
+                             "lib/libssp2vit_lab.so (scripts/build_variant.py lab -DSSP2_LAB=1; VitEngine(lib_variant=\"lab\"))", option);
+#endif
   e->opt[option] = value;
   return 0;
 }
@@ -631,6 +659,12 @@ int ssp2_query(ssp2_handle e, int what) {
     case SSP2_Q_MAX_IMAGES: return e->d.max_images;
     case SSP2_Q_TOKENS: return e->tokens;
     case SSP2_Q_IMG: return e->d.img;
+    case SSP2_Q_LAB_BUILD:
+#ifdef SSP2_LAB
+      return 1;
+#else
+      return 0;
+#endif
     case SSP2_Q_FP8_SATURATED:
     case SSP2_Q_FP8_SATURATED_RESET: {
       if (!e->fp8_sat) return 0;
@@ -1310,6 +1344,7 @@ int ssp2_linear_bf16(void* hip_stream, int epilogue, const uint16_t* a_dev, int 
       return big ? launch_gemm256<EPI_FC1, 0>(&e, g, -2) : launch_gemm_small<EPI_FC1, 0>(&e, g, -2);
     case SSP2_EPI_RESID:
       if (!x_dev || ldx < N || (ldx % 4)) return fail(SSP2_EINVAL, "linear: x / ldx");
+#ifdef SSP2_LAB
       if (big && N % 256 == 0 && K / 64 >= 4) {     // SSP2_DEFER_RESID=1: the deferred residual, as the forward would take it
         const char* v = getenv("SSP2_DEFER_RESID");
         if (v && atoi(v)) {
@@ -1319,6 +1354,7 @@ int ssp2_linear_bf16(void* hip_stream, int epilogue, const uint16_t* a_dev, int 
           return launch_gemm256<EPI_RESID, 1>(&e, g, -2);
         }
       }
+#endif
       return big ? launch_gemm256<EPI_RESID>(&e, g, -2) : launch_gemm_small<EPI_RESID>(&e, g, -2);
     default: return fail(SSP2_EINVAL, "unknown epilogue %d", epilogue);
   }

@@ -101,13 +101,23 @@ template <int EPI, int SCORE = 0, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   using C = G256;
   constexpr bool SWAP = !(EPI == EPI_FC1 && SCORE != 0);
-  constexpr int LNV = (EPI == EPI_RESID && SCORE >= 3) ? SCORE : 0;     // > 0: LayerNorm of the finished row panels, N = LNV * 256 (see below)
+  // PRODUCT vs LAB builds.  libssp2vit.so instantiates only what the forward launches: {EPI_BF16, EPI_FC1 x SCORE 0 / 1 / 2, EPI_RESID}
+  // x {bf16, e4m3}.  The forms that were built, measured and found slower — the LayerNorm behind the residual epilogue (LNV), the
+  // deferred residual (DG), the column-group tile orders (GROUP256) — stay in this file behind SSP2_LAB (lib/libssp2vit_lab.so,
+  // tools/gemm_bench: scripts/build_variant.py, _lib.build_library(variant="lab")), with their bit-identity tests run against that
+  // build: the product kernel does not carry their template instantiations, branches or registers.
+#ifdef SSP2_LAB
+  constexpr bool LAB = true;
+#else
+  constexpr bool LAB = false;
+#endif
+  constexpr int LNV = (LAB && EPI == EPI_RESID && SCORE >= 3) ? SCORE : 0;     // > 0: LayerNorm of the finished row panels, N = LNV * 256 (see below)
   // DG (EPI_RESID, SCORE == 1, bf16 operands): the DEFERRED residual.  The epilogue only PARKS the tile — bf16(acc + bias), 128 KiB per
   // workgroup in g.dg, written row-contiguous through the usual LDS transposition — and the read-add-write of the fp32 x tile
   // happens during the NEXT tile's main loop, one sixteenth of a wave's 128 x 64 window (16 rows x 32 columns: one 16-byte load of parked
   // values, two 16-byte loads of x, two stores) per K-tile, in the LOAD phase of the wave — while its SIMD partner feeds the matrix pipe.
   // x_new = x + float(bf16(acc + bias)) exactly as in the direct form, and every sum over K keeps its order: results are bit-identical.
-  constexpr bool DG = EPI == EPI_RESID && SCORE == 1 && !F8;
+  constexpr bool DG = LAB && EPI == EPI_RESID && SCORE == 1 && !F8;
   constexpr int ESZ = F8 ? 1 : 2;                       // bytes per operand element
   constexpr int KT = F8 ? 128 : GEMM_BK;                // K elements per K-tile (128 bytes per LDS row either way)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -159,8 +169,8 @@ __global__ __launch_bounds__(512) void gemm256_bf16_kernel(const GemmArgs g) {
   auto set_tile = [&](int tile) {
     int tm, tn;
     if (g.reverse) tile = ntiles - 1 - tile;
-    const int gn = g.group_m % 100, gm = g.group_m / 100;          // group_m = 100 * GM + GN (0: plain order)
-    if (gn > 0 && gn < g.tiles_n) {
+    const int gn = LAB ? g.group_m % 100 : 0, gm = LAB ? g.group_m / 100 : 0;          // group_m = 100 * GM + GN (0: plain order; lab builds only)
+    if (LAB && gn > 0 && gn < g.tiles_n) {
       // Super-tiles for the 4 MiB L2 of an XCD: blocks of GM row panels (all of them if GM = 0); inside a block column
       // groups of GN tiles, inside a group N fastest.  An XCD's 32 concurrent tiles then touch GN weight panels instead
       // of all of them, and the next column group of the block re-reads the block's A panels from L2 / Infinity Cache.

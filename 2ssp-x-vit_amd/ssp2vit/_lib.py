@@ -44,26 +44,38 @@ class Ssp2Error(RuntimeError):
     pass
 
 
-def build_library(verbose: bool = False, only_if_stale: bool = False) -> str:
+# Named builds beside the product library: lib/libssp2vit_<name>.so = the same sources with extra -D flags.  "lab" carries the opt-in
+# kernel forms the product does not instantiate (LayerNorm behind the residual epilogue, deferred residual, column-group tile orders:
+# csrc/gemm256.hip.h SSP2_LAB) — their bit-identity tests run against it (VitEngine(lib_variant="lab")).
+VARIANT_FLAGS = {"lab": ("-DSSP2_LAB=1",)}
+
+
+def variant_path(variant: Optional[str]) -> str:
+    return LIB_PATH if not variant else os.path.join(os.path.dirname(LIB_PATH), f"libssp2vit_{variant}.so")
+
+
+def build_library(verbose: bool = False, only_if_stale: bool = False, variant: Optional[str] = None, flags=()) -> str:
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Output stays in-tree: 2ssp-x-vit_amd/lib/."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           os.path.join(CSRC, "engine.hip"), "-o", LIB_PATH]
+    out = variant_path(variant)
+    flags = tuple(flags) or VARIANT_FLAGS.get(variant or "", ())
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", *flags,
+           os.path.join(CSRC, "engine.hip"), "-o", out]
     if verbose:
         print(" ".join(cmd))
     import fcntl
-    with open(LIB_PATH + ".lock", "w") as lock:          # one builder at a time (several ranks may start together)
+    with open(out + ".lock", "w") as lock:          # one builder at a time (several ranks may start together)
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if only_if_stale and not _needs_rebuild():
-            return LIB_PATH
-        tmp = LIB_PATH + f".tmp{os.getpid()}"
+        if only_if_stale and not _needs_rebuild(variant):
+            return out
+        tmp = out + f".tmp{os.getpid()}"
         cmd[-1] = tmp
         subprocess.run(cmd, check=True, cwd=CSRC)
-        os.replace(tmp, LIB_PATH)
-        with open(HASH_PATH, "w") as f:
-            f.write(_source_hash())
-    return LIB_PATH
+        os.replace(tmp, out)
+        with open(out + ".srchash", "w") as f:
+            f.write(_source_hash() + " " + " ".join(flags))
+    return out
 
 
 HASH_PATH = LIB_PATH + ".srchash"
@@ -81,11 +93,12 @@ def _source_hash() -> str:
     return h.hexdigest()
 
 
-def _needs_rebuild() -> bool:
-    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
+def _needs_rebuild(variant: Optional[str] = None) -> bool:
+    path = variant_path(variant)
+    if not os.path.exists(path) or not os.path.exists(path + ".srchash"):
         return True
-    with open(HASH_PATH) as f:
-        return f.read().strip() != _source_hash()
+    with open(path + ".srchash") as f:
+        return f.read().split()[:1] != [_source_hash()]
 
 
 TORCH_OPS_PATH = os.path.join(PKG_ROOT, "lib", "libssp2vit_torch.so")
@@ -160,6 +173,8 @@ def build_tool(name: str, defines=(), out: Optional[str] = None) -> str:
     if os.path.exists(exe) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return exe
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not any(d.startswith("-DSSP2_LAB") for d in defines):
+        defines = ("-DSSP2_LAB=1", *defines)             # the micro-benchmarks exercise the lab forms too (gemm_bench epi 15, GEMM_SUSTAIN of the deferred residual)
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", *defines, src, "-o", exe],
                    check=True, cwd=TOOLS, timeout=900)
     with open(stamp, "w") as f:
@@ -167,25 +182,31 @@ def build_tool(name: str, defines=(), out: Optional[str] = None) -> str:
     return exe
 
 
-_lib: Optional[C.CDLL] = None
+_libs: dict = {}
 
 
-def load(build_if_missing: bool = True) -> C.CDLL:
-    global _lib
-    if _lib is not None:
-        return _lib
-    variant = os.environ.get("SSP2_LIB_VARIANT")          # A/B runs only (scripts/build_variant.py): lib/libssp2vit_<variant>.so, built with extra -D flags
-    if variant:
-        path = os.path.join(os.path.dirname(LIB_PATH), f"libssp2vit_{variant}.so")
+def load(build_if_missing: bool = True, variant: Optional[str] = None) -> C.CDLL:
+    """The product library, or a named build of the same sources (`variant`; default: SSP2_LIB_VARIANT from the environment, for A/B
+    runs).  A known variant ("lab") is built like the product when missing or stale; any other must exist (scripts/build_variant.py).
+    Every library is checked against this binding's ABI version before a symbol is touched."""
+    variant = variant or os.environ.get("SSP2_LIB_VARIANT") or None
+    if variant in _libs:
+        return _libs[variant]
+    path = variant_path(variant)
+    if variant and variant not in VARIANT_FLAGS:
         if not os.path.exists(path):
-            raise Ssp2Error(f"SSP2_LIB_VARIANT={variant}: {path} does not exist (scripts/build_variant.py builds it)")
-    else:
-        path = LIB_PATH
-        if _needs_rebuild():
-            if not build_if_missing:
-                raise Ssp2Error(f"{LIB_PATH} missing or stale; run `python -c 'import __graft_entry__ as g; g.build()'`")
-            build_library(only_if_stale=True)
+            raise Ssp2Error(f"library variant {variant!r}: {path} does not exist (scripts/build_variant.py builds it)")
+    elif _needs_rebuild(variant):
+        if not build_if_missing:
+            raise Ssp2Error(f"{path} missing or stale; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        build_library(only_if_stale=True, variant=variant)
     lib = C.CDLL(path)
+    lib.ssp2_abi_version.restype = C.c_int
+    if lib.ssp2_abi_version() != ABI_VERSION:
+        raise Ssp2Error(f"{path}: ABI {lib.ssp2_abi_version()} but this binding speaks ABI {ABI_VERSION} — a stale variant build; rebuild it")
+    missing = [n for n in SYMBOLS if not hasattr(lib, n)]
+    if missing:
+        raise Ssp2Error(f"{path} lacks {missing}: a stale variant build; rebuild it")
     vp, i32, i64p = C.c_void_p, C.c_int, C.POINTER(C.c_int64)
     lib.ssp2_abi_version.restype = i32
     lib.ssp2_last_error.restype = C.c_char_p
@@ -235,11 +256,12 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("ssp2_last_error", "ssp2_workspace_bytes", "ssp2_rows", "ssp2_fp8_attn_scale"):
             fn.restype = i32
-    _lib = lib
+    _libs[variant] = lib
     return lib
 
 
-def check(rc: int) -> None:
+def check(rc: int, lib: Optional[C.CDLL] = None) -> None:
+    """`lib`: the library the failing call went to (every build keeps its own last-error text); default: the product library."""
     if rc != 0:
-        msg = load().ssp2_last_error()
+        msg = (lib or load()).ssp2_last_error()
         raise Ssp2Error(f"libssp2vit error {rc}: {msg.decode() if msg else '?'}")

@@ -17,8 +17,14 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class VitEngine:
+    def _check(self, rc: int) -> None:
+        check(rc, self.lib)
+
     def __init__(self, weights: Optional[Dict], device: str | torch.device = "cuda:0", max_images: int = 64, *,
-                 precision: str = "bf16", _twin_of: Optional["VitEngine"] = None, _d_int: Optional[Sequence[int]] = None):
+                 precision: str = "bf16", lib_variant: Optional[str] = None, _twin_of: Optional["VitEngine"] = None,
+                 _d_int: Optional[Sequence[int]] = None):
+        """`lib_variant`: a named build of the library instead of the product one — "lab" carries the opt-in kernel forms the product
+        does not instantiate (options ln_fusion / defer_resid / group256; ssp2vit/_lib.py VARIANT_FLAGS)."""
         if precision not in ("bf16", "fp8"):
             raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
         self.precision = precision
@@ -34,7 +40,8 @@ class VitEngine:
             raise Ssp2Error(f"ssp2vit runs on HIP devices only, got device={device!r}")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.lib = _lib.load()
+        self.lib_variant = lib_variant if _twin_of is None else _twin_of.lib_variant
+        self.lib = _lib.load(variant=self.lib_variant)
         self.depth = int(weights["depth"])
         self.dim = int(weights["dim"])
         self.classes = int(weights["classes"])
@@ -49,17 +56,17 @@ class VitEngine:
                        float(weights.get("eps", 1e-6)), self.max_images, arr)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            check(self.lib.ssp2_create(C.byref(desc), C.byref(h)))
+            self._check(self.lib.ssp2_create(C.byref(desc), C.byref(h)))
             self.h = h
             self.tokens = self.lib.ssp2_tokens(self.h)
             if _twin_of is None:
                 self._load(weights)
                 if precision == "fp8":
                     self._bind_stream()
-                    check(self.lib.ssp2_set_precision(self.h, 1))
+                    self._check(self.lib.ssp2_set_precision(self.h, 1))
             else:
                 self._bind_stream()
-                check(self.lib.ssp2_clone_weights(self.h, _twin_of.h))
+                self._check(self.lib.ssp2_clone_weights(self.h, _twin_of.h))
                 self.absent = list(_twin_of.absent)
 
     # ------------------------------------------------------------------ weights
@@ -75,10 +82,10 @@ class VitEngine:
             if t.device == self.device:
                 t = t.to(torch.float32).contiguous()
                 keep.append(t)                                   # alive until the stream has consumed it
-                check(self.lib.ssp2_load_tensor_dev(self.h, T_KINDS.index(kind), layer, C.c_void_p(t.data_ptr()), t.numel()))
+                self._check(self.lib.ssp2_load_tensor_dev(self.h, T_KINDS.index(kind), layer, C.c_void_p(t.data_ptr()), t.numel()))
             else:
                 t = t.to("cpu", torch.float32).contiguous()
-                check(self.lib.ssp2_load_tensor(self.h, T_KINDS.index(kind), layer,
+                self._check(self.lib.ssp2_load_tensor(self.h, T_KINDS.index(kind), layer,
                                                 C.cast(t.data_ptr(), C.POINTER(C.c_float)), t.numel()))
         for k in ("patch_w", "patch_b", "cls", "pos", "lnf_g", "lnf_b", "head_w", "head_b"):
             put(k, 0, w[k])
@@ -116,7 +123,7 @@ class VitEngine:
         in HBM (reference src/vit_pruning.py:297-311 on the module).  No re-upload of weights."""
         arr = (C.c_int32 * len(keep))(*[int(k) for k in keep])
         with torch.cuda.device(self.device):
-            check(self.lib.ssp2_prune_ffn(self.h, int(layer), arr, len(keep)))
+            self._check(self.lib.ssp2_prune_ffn(self.h, int(layer), arr, len(keep)))
         self.d_int[layer] = len(keep)
 
     def apply_ffn_masks(self, masks: Sequence[Sequence[int]]) -> None:
@@ -128,22 +135,22 @@ class VitEngine:
 
     def drop_attention(self, layers: Sequence[int]) -> None:
         for l in layers:
-            check(self.lib.ssp2_drop_attention(self.h, int(l)))
+            self._check(self.lib.ssp2_drop_attention(self.h, int(l)))
             self.absent[int(l)] = True
 
     def set_cu_limit(self, n_cu: int) -> None:
         """Cap the grids of this engine's persistent kernels at n_cu workgroups (0 = all CUs)."""
-        check(self.lib.ssp2_set_cu_limit(self.h, int(n_cu)))
+        self._check(self.lib.ssp2_set_cu_limit(self.h, int(n_cu)))
 
     def set_option(self, name: str, value: int) -> None:
         """Run-time switch of this engine (include/ssp2vit.h SSP2_OPT_*: "zigzag", "attn_persist", "ln_fusion", "big_tiles",
         "fc1_big_tiles", "group256").  None of them changes a result bit; they exist for the tests and A/B scripts that prove it."""
-        check(self.lib.ssp2_set_option(self.h, OPTIONS[name], int(value)))
+        self._check(self.lib.ssp2_set_option(self.h, OPTIONS[name], int(value)))
 
     def get_option(self, name: str) -> int:
         v = self.lib.ssp2_get_option(self.h, OPTIONS[name])
         if v < 0:
-            check(v)
+            self._check(v)
         return int(v)
 
     def calibrate_fp8(self, pixels: torch.Tensor, headroom: float = 4.0) -> List[float]:
@@ -154,14 +161,14 @@ class VitEngine:
         if self.precision != "fp8":
             raise Ssp2Error("calibrate_fp8 needs precision='fp8'")
         self._bind_stream()
-        check(self.lib.ssp2_fp8_calibrate_begin(self.h))
+        self._check(self.lib.ssp2_fp8_calibrate_begin(self.h))
         try:
             for s0 in range(0, pixels.shape[0], self.max_images):      # EVERY block through the full path (forward_logits ends in the CLS-only tail)
                 chunk = pixels[s0:s0 + self.max_images]
                 x = self.embed(chunk)
                 self.layers(x, chunk.shape[0], 0, self.depth)
         finally:
-            check(self.lib.ssp2_fp8_calibrate_end(self.h, float(headroom)))
+            self._check(self.lib.ssp2_fp8_calibrate_end(self.h, float(headroom)))
         return [float(self.lib.ssp2_fp8_attn_scale(self.h, l)) for l in range(self.depth)]
 
     def fp8_saturation(self, reset: bool = False) -> int:
@@ -170,7 +177,7 @@ class VitEngine:
         says this checkpoint wants `set_option("fp8_proj", 0)` or bf16.  Waits for the stream."""
         v = self.lib.ssp2_query(self.h, 8 if reset else 7)            # SSP2_Q_FP8_SATURATED_RESET / SSP2_Q_FP8_SATURATED
         if v < 0:
-            check(v)
+            self._check(v)
         return int(v)
 
     def pruned_twin(self, d_int: Sequence[int], max_images: int = 64) -> "VitEngine":
@@ -193,7 +200,7 @@ class VitEngine:
         for l, m in enumerate(masks):
             keep = m if isinstance(m, torch.Tensor) else torch.as_tensor(m)
             keep = torch.nonzero(keep == 0).view(-1).to(torch.int32).contiguous()
-            check(self.lib.ssp2_prune_ffn_into(twin.h, self.h, l, C.cast(keep.data_ptr(), C.POINTER(C.c_int32)), keep.numel()))
+            self._check(self.lib.ssp2_prune_ffn_into(twin.h, self.h, l, C.cast(keep.data_ptr(), C.POINTER(C.c_int32)), keep.numel()))
         return twin
 
     def apply_attention_into(self, twin: "VitEngine", drop_blocks: Sequence[int]) -> "VitEngine":
@@ -201,14 +208,14 @@ class VitEngine:
         drop = set(int(b) for b in drop_blocks)
         for l in range(self.depth):
             if l in drop or self.absent[l]:
-                check(self.lib.ssp2_drop_attention(twin.h, l)); twin.absent[l] = True
+                self._check(self.lib.ssp2_drop_attention(twin.h, l)); twin.absent[l] = True
             else:
-                check(self.lib.ssp2_restore_attention(twin.h, l)); twin.absent[l] = False
+                self._check(self.lib.ssp2_restore_attention(twin.h, l)); twin.absent[l] = False
         return twin
 
     # ------------------------------------------------------------------ plumbing
     def _bind_stream(self) -> None:
-        check(self.lib.ssp2_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        self._check(self.lib.ssp2_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def _skip_array(self, attn_skip: Optional[Sequence[int]]):
         flags = [1 if a else 0 for a in self.absent]
@@ -260,7 +267,7 @@ class VitEngine:
         n = px.shape[0]
         x = self.new_x(n, group) if x is None else x
         self._bind_stream()
-        check(self.lib.ssp2_embed(self.h, _ptr(px), n, _ptr(x), int(group)))
+        self._check(self.lib.ssp2_embed(self.h, _ptr(px), n, _ptr(x), int(group)))
         return x
 
     def layers(self, x: torch.Tensor, n: int, l_begin: int = 0, l_end: Optional[int] = None,
@@ -281,7 +288,7 @@ class VitEngine:
         self._bind_stream()
         if x_in is not None and (x_in.shape[0] < x.shape[0] or x_in.shape[1:] != x.shape[1:] or x_in.dtype != x.dtype or not x_in.is_contiguous()):
             raise ValueError("x_in must be a contiguous stream of the shape of x")
-        check(self.lib.ssp2_layers_prefix(self.h, _ptr(x_in), _ptr(x), n, l_begin, l_end, self._skip_array(attn_skip), site,
+        self._check(self.lib.ssp2_layers_prefix(self.h, _ptr(x_in), _ptr(x), n, l_begin, l_end, self._skip_array(attn_skip), site,
                                           SCORE_CHAIN[score_chain], int(score_group), ns, _ptr(batch_scores if site else None), self.score_ld))
         return batch_scores if site else None
 
@@ -294,7 +301,7 @@ class VitEngine:
             if correct is None:
                 correct = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._bind_stream()
-        check(self.lib.ssp2_head(self.h, _ptr(x), n, int(group), _ptr(logits), _ptr(pred), _ptr(labels),
+        self._check(self.lib.ssp2_head(self.h, _ptr(x), n, int(group), _ptr(logits), _ptr(pred), _ptr(labels),
                                  _ptr(correct if labels is not None else None)))
         return logits, pred, correct
 
@@ -317,7 +324,7 @@ class VitEngine:
                 raise ValueError("`correct` needs one contiguous int64 entry per slot")
         skip_last = bool(self.absent[self.depth - 1]) or (attn_skip is not None and (self.depth - 1) in [int(i) for i in attn_skip])
         self._bind_stream()
-        check(self.lib.ssp2_tail_group(self.h, _ptr(x), n, int(slots), int(group), int(skip_last), _ptr(logits), _ptr(pred), _ptr(labels),
+        self._check(self.lib.ssp2_tail_group(self.h, _ptr(x), n, int(slots), int(group), int(skip_last), _ptr(logits), _ptr(pred), _ptr(labels),
                                        _ptr(correct if labels is not None else None)))
         return logits, pred, correct
 
@@ -329,7 +336,7 @@ class VitEngine:
         dtype = {torch.bfloat16: 0, torch.float32: 1}[act.dtype]
         ws = torch.empty(2, n, d, dtype=torch.float32, device=act.device)
         out = torch.empty(d, dtype=torch.float32, device=act.device)
-        check(self.lib.ssp2_act_l2_accum(C.c_void_p(torch.cuda.current_stream(act.device).cuda_stream), _ptr(act), dtype,
+        self._check(self.lib.ssp2_act_l2_accum(C.c_void_p(torch.cuda.current_stream(act.device).cuda_stream), _ptr(act), dtype,
                                          n, t, d, d, SCORE_CHAIN[score_chain], 0, _ptr(ws), _ptr(out), d))
         return out
 
@@ -351,7 +358,7 @@ class VitEngine:
         out = None if epi == 1 else torch.empty(M, N, dtype=torch.bfloat16, device=self.device)
         if epi == 1 and (x is None or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[1] != N or x.shape[0] < M):
             raise ValueError("resid epilogue needs a contiguous f32 x [>= M, N]")
-        check(self.lib.ssp2_linear_bf16(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), epi, _ptr(a), K,
+        self._check(self.lib.ssp2_linear_bf16(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), epi, _ptr(a), K,
                                         _ptr(wp), K, _ptr(bp), M, N, K, _ptr(out), N, _ptr(x if epi == 1 else None), N,
                                         {"auto": 0, "small": 1, "big": 2}[kernel]))
         return x if epi == 1 else out
@@ -385,7 +392,7 @@ class VitEngine:
         class _Ctx:
             def __enter__(self_inner):
                 eng._bind_stream()
-                check(eng.lib.ssp2_profile_begin(eng.h, len(K_CLASS) if klass == "all" else K_CLASS[klass]))
+                eng._check(eng.lib.ssp2_profile_begin(eng.h, len(K_CLASS) if klass == "all" else K_CLASS[klass]))
                 return self_inner
 
             def __exit__(self_inner, *exc):
@@ -394,10 +401,10 @@ class VitEngine:
                     self_inner.by_class = {}
                     for name, k in K_CLASS.items():
                         by = C.c_double()
-                        check(eng.lib.ssp2_profile_query(eng.h, k, C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by)))
+                        eng._check(eng.lib.ssp2_profile_query(eng.h, k, C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by)))
                         if cnt.value:
                             self_inner.by_class[name] = {"ms": ms.value, "launches": cnt.value, "flops": fl.value, "bytes": by.value}
-                check(eng.lib.ssp2_profile_end(eng.h, C.byref(ms), C.byref(cnt), C.byref(fl)))
+                eng._check(eng.lib.ssp2_profile_end(eng.h, C.byref(ms), C.byref(cnt), C.byref(fl)))
                 self_inner.total_ms, self_inner.launches, self_inner.flops = ms.value, cnt.value, fl.value
                 return False
         return _Ctx()

@@ -85,6 +85,8 @@ int ssp2_set_cu_limit(ssp2_handle h, int n_cu);
  * each one and compares).  Defaults come from the environment variable named beside each, read once in ssp2_create.
  *   SSP2_OPT_ZIGZAG         1  SSP2_ZIGZAG          large launches walk their row panels opposite to the previous launch
  *   SSP2_OPT_ATTN_PERSIST   1  SSP2_ATTN_PERSIST    d_h = 64 / 80 attention on the persistent producer / consumer kernel
+ * (LAB-BUILD ONLY — lib/libssp2vit_lab.so, -DSSP2_LAB; the product library refuses a non-zero value with SSP2_ESTATE: SSP2_OPT_LN_FUSION,
+ *  SSP2_OPT_GROUP256, SSP2_OPT_DEFER_RESID.  All three were measured slower than the default and are kept for their bit-identity tests.)
  *   SSP2_OPT_LN_FUSION      0  SSP2_LN_FUSION       LayerNorm inside the residual GEMM (the panel's last-arriving workgroup normalises it): 0 off, 1 / 2 on for every eligible launch
  *   SSP2_OPT_BIG_TILES      1  SSP2_NO_BIG_TILES    launches with >= 4096 rows on the persistent 256 x 256 GEMM
  *   SSP2_OPT_FC1_BIG_TILES  1  SSP2_FC1_SMALL_TILES fc1 of such launches too
@@ -277,7 +279,8 @@ int ssp2_profile_end(ssp2_handle h, double* total_ms, int64_t* launches, double*
  * carry per-row scales and cannot clip; the GELU output that fc2 reads is cast unscaled and NOT counted — it clips beyond 448, and
  * counting in that epilogue costs the fc1 kernels the registers they do not have: 20-188 spilled bytes per lane when it was tried.) */
 enum { SSP2_Q_DIM = 0, SSP2_Q_DEPTH, SSP2_Q_CLASSES, SSP2_Q_SCORE_LD /* max ceil64(d_int) */, SSP2_Q_MAX_IMAGES, SSP2_Q_TOKENS, SSP2_Q_IMG,
-       SSP2_Q_FP8_SATURATED, SSP2_Q_FP8_SATURATED_RESET };
+       SSP2_Q_FP8_SATURATED, SSP2_Q_FP8_SATURATED_RESET,
+       SSP2_Q_LAB_BUILD /* 1: this library was built with -DSSP2_LAB (carries the opt-in kernel forms SSP2_OPT_LN_FUSION / _DEFER_RESID / _GROUP256); 0: the product build */ };
 int ssp2_query(ssp2_handle h, int what);                                  /* >= 0, or SSP2_EINVAL */
 int ssp2_tokens(ssp2_handle h);
 size_t ssp2_workspace_bytes(ssp2_handle h);

@@ -17,6 +17,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "lab: a VARIANT test — runs against lib/libssp2vit_lab.so (-DSSP2_LAB: the opt-in kernel forms the "
+                                       "product library does not instantiate), with the product library as the source of the expected bits")
 
 
 def load_tiny_golden(layout: str):

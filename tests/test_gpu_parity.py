@@ -1690,6 +1690,7 @@ def test_config4_at_its_stated_size_4096_calibration_images_vit_h14(gpu):
                                                  # missing wait state in front of an inline-asm load showed (csrc/gemm256.hip.h load_row)
                                                  ("vit_base_patch16_224_d3", "bf16", 640), ("vit_huge_patch14_224_d2", "bf16", 320),
                                                  ("vit_huge_patch14_224_d2", "fp8", 320)])
+@pytest.mark.lab
 def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_bits(gpu, cfg, precision, n_img, monkeypatch):
     """SSP2_OPT_LN_FUSION (opt-in, csrc/engine.hip ln_fusable; ssp2_set_option): the attention out-projection and fc2 of a launch with >= 4096
     rows normalise the row panels they finish inside the GEMM kernel (gemm256.hip.h, LNV = dim / 256 = 3, 4, 5; per-XCD tile
@@ -1702,19 +1703,30 @@ def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_
     from ssp2vit.weights import synthetic_weights
     w = synthetic_weights(cfg, classes=10, seed=5, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
     depth = int(w["depth"])
-    eng = VitEngine(w, max_images=n_img, precision=precision)
     g = torch.Generator().manual_seed(9)
     px = torch.randn(n_img, 3, 224, 224, generator=g).to(gpu)          # 40 x 197 = 7880 / 40 x 257 = 10280 rows: a ragged last panel
     skips = [None] + ([[1]] if depth > 2 else []) + [[0], [depth - 1]]
-    def run():
+    def run(e=None):
+        e = e or eng
         out = []
         for sk in skips:
-            out.append(eng.forward_logits(px, attn_skip=sk).cpu())
+            out.append(e.forward_logits(px, attn_skip=sk).cpu())
         for site in ("pre_gelu", "post_gelu"):
-            out.append(eng.forward_scores(px, site)[0].cpu())
+            out.append(e.forward_scores(px, site)[0].cpu())
         return out
+    # round 5: the fused form lives in the LAB build only (lib/libssp2vit_lab.so, -DSSP2_LAB); the reference bits come from the PRODUCT library
+    prod = VitEngine(w, max_images=n_img, precision=precision)
+    from ssp2vit._lib import Ssp2Error
+    with pytest.raises(Ssp2Error):
+        prod.set_option("ln_fusion", 1)                                 # the product build refuses what it does not instantiate
+    assert prod.lib.ssp2_query(prod.h, 9) == 0                          # SSP2_Q_LAB_BUILD
+    plain = run(prod)
+    prod.close()
+    eng = VitEngine(w, max_images=n_img, precision=precision, lib_variant="lab")
+    assert eng.lib.ssp2_query(eng.h, 9) == 1
     eng.set_option("ln_fusion", 0)
-    plain = run()
+    for a, b in zip(plain, run()):                                      # the lab build with the switch off: the product's bits
+        assert torch.equal(a, b)
     eng.set_option("ln_fusion", 2)
     assert eng.get_option("ln_fusion") == 2
     fused = run()
@@ -1982,6 +1994,7 @@ def test_two_and_three_ranks_sharing_the_card_equal_the_single_rank_result(gpu, 
 @pytest.mark.parametrize("cfg,n_img", [("vit_base_patch16_224_d3", 40), ("vit_large_patch16_224_d2", 40), ("vit_huge_patch14_224_d2", 40),
                                        # several tiles per workgroup: every tile but a workgroup's first rides on a predecessor, the last one drains alone
                                        ("vit_base_patch16_224_d3", 640), ("vit_huge_patch14_224_d2", 320)])
+@pytest.mark.lab
 def test_deferred_residual_gives_the_direct_epilogues_bits(gpu, cfg, n_img):
     """SSP2_OPT_DEFER_RESID (opt-in; csrc/gemm256.hip.h, DG): the residual projections on the persistent 256 x 256 GEMM only PARK
     bf16(acc + bias) in their epilogue and add it to the fp32 x tile during the NEXT tile's main loop, one sixteenth of a wave's window
@@ -1994,18 +2007,33 @@ def test_deferred_residual_gives_the_direct_epilogues_bits(gpu, cfg, n_img):
     from ssp2vit.weights import synthetic_weights
     w = synthetic_weights(cfg, classes=10, seed=5, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
     depth = int(w["depth"])
-    eng = VitEngine(w, max_images=max(n_img, depth * 40))
     g = torch.Generator().manual_seed(9)
     px = torch.randn(n_img, 3, 224, 224, generator=g).to(gpu)
     labels = torch.randint(0, 10, (40,), generator=g)
-    def run():
+    def run(eng):
         out = [eng.forward_logits(px, attn_skip=sk).cpu() for sk in (None, [0], [depth - 1])]
         out += [eng.forward_scores(px, site)[0].cpu() for site in ("pre_gelu", "post_gelu")]
         out.append(core.depth_search_counts(eng, [{"pixel_values": px[:40], "labels": labels}], depth, batch_limit=None))
         return out
+    # round 5: the deferred form lives in the LAB build only; the direct epilogue's bits come from the PRODUCT library
+    prod = VitEngine(w, max_images=max(n_img, depth * 40))
+    from ssp2vit._lib import Ssp2Error
+    with pytest.raises(Ssp2Error):
+        prod.set_option("defer_resid", 1)
+    with pytest.raises(Ssp2Error):
+        prod.set_option("group256", 806)
+    direct = run(prod)
+    prod.close()
+    eng = VitEngine(w, max_images=max(n_img, depth * 40), lib_variant="lab")
     assert eng.get_option("defer_resid") == 0                         # opt-in: measured slower than the direct form
-    direct = run()
+    for a, b in zip(direct, run(eng)):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+    eng.set_option("group256", 806)                                   # column-group tile order (lab): no bit moves either
+    for a, b in zip(direct, run(eng)):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+    eng.set_option("group256", 0)
     eng.set_option("defer_resid", 1)
+    run = (lambda f: (lambda: f(eng)))(run)
     deferred = run()
     for a, b in zip(direct, deferred):
         if torch.is_tensor(a):
