@@ -101,6 +101,9 @@ struct ssp2_engine {
   // getenv on every launch); tests and A/B scripts flip them per handle.
   int opt[SSP2_OPT_COUNT] = {};
   std::vector<void*> allocs;
+  int arena_mode = 0;                       // ssp2_create: 1 = measuring pass, 2 = assigning pass (dalloc)
+  size_t arena_need[2] = {0, 0};            // [0] zero-initialised, [1] written before read
+  char* arena_cur[2] = {nullptr, nullptr};
   size_t ws_bytes = 0, weight_bytes = 0;
 
   Mat patch, head;
@@ -157,13 +160,30 @@ struct ssp2_engine {
 static const int kMaxDevices = 64;
 static inline int cur_device() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices) ? d : 0; }
 
+// ssp2_create runs its allocation sequence TWICE: a measuring pass (arena_mode 1: sizes only), then ONE hipMalloc + ONE hipMemset for
+// everything that must start as zeros and ONE hipMalloc for the buffers that are always written before they are read (qkv, FFN activation:
+// 8 of the 10.5 GB of a layer-major ViT-B/16 workspace), then the assigning pass (arena_mode 2).  Rounds 1-4 issued ~250 hipMalloc + 250
+// synchronous hipMemset per engine and zeroed all of it: 4 ms of every prune through the reference-named API, whose engine is built
+// inside the prune bracket.  Outside ssp2_create (arena_mode 0: fp8 weight images, on-demand buffers) every buffer is its own allocation.
 template <typename T>
-static int dalloc(ssp2_engine* e, T** p, size_t count, bool workspace) {
+static int dalloc(ssp2_engine* e, T** p, size_t count, bool workspace, bool zero = true) {
   void* q = nullptr;
   size_t bytes = count * sizeof(T);
   if (bytes == 0) bytes = 16;
+  if (e->arena_mode == 1) {
+    e->arena_need[zero ? 0 : 1] += (bytes + 255) & ~(size_t)255;
+    *p = nullptr;
+    return 0;
+  }
+  if (e->arena_mode == 2) {
+    char*& cur = e->arena_cur[zero ? 0 : 1];
+    *p = (T*)cur;
+    cur += (bytes + 255) & ~(size_t)255;
+    (workspace ? e->ws_bytes : e->weight_bytes) += bytes;
+    return 0;
+  }
   if (hipMalloc(&q, bytes) != hipSuccess) return fail(SSP2_ENOMEM, "hipMalloc(%zu) failed", bytes);
-  if (hipMemset(q, 0, bytes) != hipSuccess) return fail(SSP2_EHIP, "hipMemset failed");
+  if (zero && hipMemset(q, 0, bytes) != hipSuccess) return fail(SSP2_EHIP, "hipMemset failed");
   e->allocs.push_back(q);
   (workspace ? e->ws_bytes : e->weight_bytes) += bytes;
   *p = (T*)q;
@@ -506,50 +526,70 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
   }
   int rc = 0;
 #define TRY(x) do { if ((rc = (x))) { ssp2_destroy(e); return rc; } } while (0)
-  TRY(mat_alloc(e, e->patch, d.dim, e->kpe));
-  TRY(mat_alloc(e, e->head, d.classes, d.dim));
-  TRY(dalloc(e, &e->cls, d.dim, false));
-  TRY(dalloc(e, &e->pos, (size_t)e->tokens * d.dim, false));
-  TRY(dalloc(e, &e->lnf_g, d.dim, false));
-  TRY(dalloc(e, &e->lnf_b, d.dim, false));
+#define TRYA(x) do { if (int rc_ = (x)) return rc_; } while (0)
+  auto alloc_all = [&]() -> int {
+  TRYA(mat_alloc(e, e->patch, d.dim, e->kpe));
+  TRYA(mat_alloc(e, e->head, d.classes, d.dim));
+  TRYA(dalloc(e, &e->cls, d.dim, false));
+  TRYA(dalloc(e, &e->pos, (size_t)e->tokens * d.dim, false));
+  TRYA(dalloc(e, &e->lnf_g, d.dim, false));
+  TRYA(dalloc(e, &e->lnf_b, d.dim, false));
   e->layers.resize(d.depth);
+  e->ld_int_max = 0;
   for (int l = 0; l < d.depth; ++l) {
     Layer& L = e->layers[l];
     L.d_int = e->d_int[l];
-    if (L.d_int <= 0) { ssp2_destroy(e); return fail(SSP2_EINVAL, "d_int[%d] = %d", l, L.d_int); }
+    if (L.d_int <= 0) return fail(SSP2_EINVAL, "d_int[%d] = %d", l, L.d_int);
     L.ld_int = ceil_to(L.d_int, GEMM_BK);
     e->ld_int_max = L.ld_int > e->ld_int_max ? L.ld_int : e->ld_int_max;
-    TRY(dalloc(e, &L.ln1_g, d.dim, false)); TRY(dalloc(e, &L.ln1_b, d.dim, false));
-    TRY(dalloc(e, &L.ln2_g, d.dim, false)); TRY(dalloc(e, &L.ln2_b, d.dim, false));
-    TRY(mat_alloc(e, L.qkv, 3 * d.dim, d.dim));
-    TRY(mat_alloc(e, L.proj, d.dim, d.dim));
-    TRY(mat_alloc(e, L.fc1, L.d_int, d.dim));
-    TRY(mat_alloc(e, L.fc2, d.dim, L.d_int));
+    TRYA(dalloc(e, &L.ln1_g, d.dim, false)); TRYA(dalloc(e, &L.ln1_b, d.dim, false));
+    TRYA(dalloc(e, &L.ln2_g, d.dim, false)); TRYA(dalloc(e, &L.ln2_b, d.dim, false));
+    TRYA(mat_alloc(e, L.qkv, 3 * d.dim, d.dim));
+    TRYA(mat_alloc(e, L.proj, d.dim, d.dim));
+    TRYA(mat_alloc(e, L.fc1, L.d_int, d.dim));
+    TRYA(mat_alloc(e, L.fc2, d.dim, L.d_int));
   }
   e->rows_cap = (long)d.max_images * e->tokens + 16 * 256;     // slack: up to 16 padded slabs per call
   const size_t M = (size_t)e->rows_cap;
   const size_t tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   // (a_pe, the im2col image of the old patch-embed path, is allocated only if SSP2_OPT_PATCH_LDS is switched off: see ssp2_embed)
-  TRY(dalloc(e, &e->hbuf, M * d.dim, true));
-  TRY(dalloc(e, &e->qkvbuf, M * 3 * d.dim, true));
-  TRY(dalloc(e, &e->obuf, M * d.dim, true));
-  TRY(dalloc(e, &e->actbuf, M * e->ld_int_max, true));
-  if (e->tokens < GEMM_BM) TRY(dalloc(e, &e->prebuf, M * e->ld_int_max, true));
-  TRY(dalloc(e, &e->slab, tiles_m * 2 * e->ld_int_max, true));
-  TRY(dalloc(e, &e->norms, (size_t)2 * d.max_images * e->ld_int_max, true));   // [2 token halves][n][ld] for the standalone L2 kernel
-  TRY(dalloc(e, &e->cls_h, (size_t)d.max_images * d.dim, true));
-  TRY(dalloc(e, &e->x_cls, (size_t)d.max_images * d.dim, true));
-  TRY(dalloc(e, &e->q_cls, (size_t)d.max_images * d.dim, true));
-  TRY(dalloc(e, &e->o_cls, (size_t)d.max_images * d.dim, true));
-  TRY(dalloc(e, &e->h_cls, (size_t)d.max_images * d.dim, true));
-  TRY(dalloc(e, &e->act_cls, (size_t)d.max_images * e->ld_int_max, true));
-  TRY(dalloc(e, &e->logits, (size_t)d.max_images * d.classes, true));
-  TRY(dalloc(e, &e->ln_sync, (size_t)16 + (M + 255) / 256 + 1, true));
+  TRYA(dalloc(e, &e->hbuf, M * d.dim, true));
+  TRYA(dalloc(e, &e->qkvbuf, M * 3 * d.dim, true, false));      // every row of a launch is written by the QKV GEMM before the attention reads it
+  TRYA(dalloc(e, &e->obuf, M * d.dim, true));
+  TRYA(dalloc(e, &e->actbuf, M * e->ld_int_max, true, false));   // ... and by fc1 before fc2 reads it (pad columns included: zero weight rows)
+  if (e->tokens < GEMM_BM) TRYA(dalloc(e, &e->prebuf, M * e->ld_int_max, true, false));
+  TRYA(dalloc(e, &e->slab, tiles_m * 2 * e->ld_int_max, true));
+  TRYA(dalloc(e, &e->norms, (size_t)2 * d.max_images * e->ld_int_max, true));   // [2 token halves][n][ld] for the standalone L2 kernel
+  TRYA(dalloc(e, &e->cls_h, (size_t)d.max_images * d.dim, true));
+  TRYA(dalloc(e, &e->x_cls, (size_t)d.max_images * d.dim, true));
+  TRYA(dalloc(e, &e->q_cls, (size_t)d.max_images * d.dim, true));
+  TRYA(dalloc(e, &e->o_cls, (size_t)d.max_images * d.dim, true));
+  TRYA(dalloc(e, &e->h_cls, (size_t)d.max_images * d.dim, true));
+  TRYA(dalloc(e, &e->act_cls, (size_t)d.max_images * e->ld_int_max, true));
+  TRYA(dalloc(e, &e->logits, (size_t)d.max_images * d.classes, true));
+  TRYA(dalloc(e, &e->ln_sync, (size_t)16 + (M + 255) / 256 + 1, true));
 #ifdef SSP2_LAB
-  TRY(dalloc(e, &e->dg_scratch, (size_t)std::max(e->n_cu, 1) * 32768, true));      // 128 KiB per workgroup of the persistent GEMM (deferred residual, lab build)
+  TRYA(dalloc(e, &e->dg_scratch, (size_t)std::max(e->n_cu, 1) * 32768, true));      // 128 KiB per workgroup of the persistent GEMM (deferred residual, lab build)
 #endif
+    return 0;
+  };
+  e->arena_mode = 1;                                            // sizes
+  TRY(alloc_all());
+  for (int k = 0; k < 2; ++k) {
+    void* q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(e->arena_need[k], 256)) != hipSuccess) { ssp2_destroy(e); return fail(SSP2_ENOMEM, "hipMalloc(%zu) failed", e->arena_need[k]); }
+    e->allocs.push_back(q);
+    e->arena_cur[k] = (char*)q;
+  }
+  if (hipMemset(e->arena_cur[0], 0, std::max<size_t>(e->arena_need[0], 256)) != hipSuccess) { ssp2_destroy(e); return fail(SSP2_EHIP, "hipMemset failed"); }
+  e->arena_mode = 2;                                            // pointers
+  e->ws_bytes = e->weight_bytes = 0;
+  TRY(alloc_all());
+  e->arena_mode = 0;
+#undef TRYA
 #undef TRY
-  {   // the fused LayerNorm trusts the hardware's XCC_ID to name the L2 a workgroup sits behind: look at what it reports once
+#ifdef SSP2_LAB
+  {   // the fused LayerNorm (lab build) trusts the hardware's XCC_ID to name the L2 a workgroup sits behind: look at what it reports once
     unsigned int* ids = nullptr;
     const int nb = e->n_cu > 0 ? 4 * e->n_cu : 1024;
     if (hipMalloc((void**)&ids, nb * sizeof(unsigned int)) == hipSuccess) {
@@ -564,6 +604,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
       hipFree(ids);
     }
   }
+#endif
   *out = e;
   return 0;
 }

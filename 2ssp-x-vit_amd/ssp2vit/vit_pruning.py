@@ -251,11 +251,17 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
     all_masks: List[List[int]] = []
     used_scores: List[torch.Tensor] = []
     used_drop: List[int] = []
+    todo = []                                              # (block, keep index tensor) in block order
     for b, (fc1, fc2) in enumerate(pairs):
-        w1, b1, w2 = fc1.weight, fc1.bias, fc2.weight
+        w1 = fc1.weight
         width = w1.size(0)
         if scores is not None:
-            imp = scores[b].to(w1.device)
+            # The mask step runs where the importance lives.  The reference moves it to the weights' device first (:264) — on its CPU
+            # path that is the HOST, and torch.argsort's order among tied scores differs between the host and a device sort: importances
+            # that arrive as CPU tensors (what Auto2SSPInterface hands over) are therefore sorted on the host, exactly as the CPU
+            # reference sorts them, and only the kept-index list crosses to the device (round 4 sorted them on the device: ~8 small
+            # launches and two synchronisations per block inside the prune bracket).
+            imp = scores[b] if scores[b].device.type == "cpu" else scores[b].to(w1.device)
             if imp.numel() != width:
                 raise RuntimeError("precomputed/act_l2 importance size mismatch with intermediate width")
         elif strategy == "l1":
@@ -271,17 +277,33 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
         if drop <= 0:
             continue
         keep, _ = torch.sort(torch.argsort(imp, descending=True)[: width - drop])
-        mask = torch.ones(width, dtype=torch.int16, device=keep.device)
-        mask[keep] = 0                                     # 1 = prune, 0 = keep
         if collect_masks:
+            mask = torch.ones(width, dtype=torch.int16, device=keep.device)
+            mask[keep] = 0                                 # 1 = prune, 0 = keep
             all_masks.append(mask.cpu().tolist())
             all_idx.append(torch.nonzero(mask == 1).view(-1).tolist())
-        fc1.weight = nn.Parameter(w1[keep].clone())
+        todo.append((b, keep))
+    # a8: the slicing itself (reference :297-311), one gather per tensor on the weights' device.  Host-made index lists go up in ONE copy.
+    if todo:
+        dev = pairs[todo[0][0]][0].weight.device
+        host = [k for _, k in todo if k.device.type == "cpu"]
+        if host and dev.type != "cpu":
+            flat = torch.cat(host).to(dev)
+            off, moved = 0, []
+            for k in host:
+                moved.append(flat[off:off + k.numel()]); off += k.numel()
+            it = iter(moved)
+            todo = [(b, next(it) if k.device.type == "cpu" else k) for b, k in todo]
+    for b, keep in todo:
+        fc1, fc2 = pairs[b]
+        w1, b1, w2 = fc1.weight, fc1.bias, fc2.weight
+        keep = keep.to(w1.device)
+        fc1.weight = nn.Parameter(torch.index_select(w1, 0, keep))       # == w1[keep].clone()
         if b1 is not None:
-            fc1.bias = nn.Parameter(b1[keep].clone())
+            fc1.bias = nn.Parameter(torch.index_select(b1, 0, keep))
         fc1.out_features = int(keep.numel())
         fc1.in_features = w1.size(1)
-        fc2.weight = nn.Parameter(w2[:, keep].clone())
+        fc2.weight = nn.Parameter(torch.index_select(w2, 1, keep))       # == w2[:, keep].clone()
         fc2.in_features = int(keep.numel())
     if collect_masks:
         # the reference's three keys (:313-318) + this build's cut-margin table for the very scores the masks were cut from

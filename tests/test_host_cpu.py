@@ -580,7 +580,10 @@ def test_no_hand_counted_kernel_spills_to_scratch():
             seen += 1
             if int(m.group(1)) != 0:
                 bad.append((name, int(m.group(1))))
-    assert seen >= 20, f"only {seen} hand-counted kernel instantiations found in the compiler's remarks"
+    # round 5: the PRODUCT build instantiates 10 gemm256 forms ({bf16, resid, fc1 x score 0 / 1 / 2} x {bf16, e4m3}) + the persistent attention
+    # kernels and the patch embed; the LayerNorm-fused / deferred-residual forms live in the lab build (checked when its GPU tests run)
+    assert seen >= 14, f"only {seen} hand-counted kernel instantiations found in the compiler's remarks"
+    assert sum(1 for _ in re.finditer(r"Function Name: \S*gemm256_bf16_kernel", out.stderr)) == 10, "the product library instantiates exactly the ten forms it launches"
     assert not bad, f"scratch in hand-counted kernels: {bad}"
 
 
