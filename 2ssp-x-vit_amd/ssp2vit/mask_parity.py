@@ -42,9 +42,15 @@ def mask_parity_report(scores: Sequence[torch.Tensor], n_prune_per_block: Sequen
     plus `eps`, `blocks_guaranteed`, `min_margin`.  Pure host arithmetic on the final [L][d_int] score vectors."""
     eps = eps_for_site(site) if eps is None else float(eps)          # `site`: the hook site the scores were taken at ("pre_gelu" default)
     blocks: List[Dict[str, Any]] = []
+    # equal widths (every model before a width prune): ONE descending sort of the [L, d_int] matrix instead of L of them — the report is
+    # this build's addition to prune_vit_mlp_width's result and sits inside the prune bracket of the reference-named API (3.8 -> 0.6 ms)
+    pre_sorted = None
+    widths = {int(t.numel()) for t in scores}
+    if len(scores) > 1 and len(widths) == 1:
+        # (sorted as fp32 — every score chain yields fp32-representable values — and widened afterwards: torch's 2-D float64 sort is 40 x slower)
+        pre_sorted = torch.sort(torch.stack([t.detach().to("cpu", torch.float32).view(-1) for t in scores]), dim=1, descending=True).values.double()
     for b, imp in enumerate(scores):
-        imp = imp.detach().to("cpu", torch.float64).view(-1)
-        width = imp.numel()
+        width = int(imp.numel())
         drop = int(n_prune_per_block[b])
         if width - drop < min_remaining:
             drop = max(0, width - min_remaining)
@@ -52,7 +58,7 @@ def mask_parity_report(scores: Sequence[torch.Tensor], n_prune_per_block: Sequen
             blocks.append({"block": b, "pruned": max(0, min(drop, width)), "cut_margin": None, "tie_band": 0,
                            "exact_ties": 0, "guaranteed": True})
             continue
-        s = torch.sort(imp, descending=True).values
+        s = pre_sorted[b] if pre_sorted is not None else torch.sort(imp.detach().to("cpu", torch.float64).view(-1), descending=True).values
         kept_min, pruned_max = float(s[width - drop - 1]), float(s[width - drop])
         margin = (kept_min - pruned_max) / kept_min if kept_min > 0 else 0.0
         kept, pruned = s[: width - drop], s[width - drop:]

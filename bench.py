@@ -489,8 +489,9 @@ def api_level(args, weights, calib, evalb, plan, dev, steps=3, search_batches=No
     t = sorted(times[1:])
     return {"prune_time_s": round(t[len(t) // 2], 4), "steps": steps, "all_s": [round(x, 4) for x in times[1:]],
             "selected_blocks": last,
-            "path": "EngineViT(weights).to(device) -> Auto2SSPInterface (deferred att + mlp importances) -> prune_vit_mlp_width("
-                    "precomputed_importance) -> prune_vit_attention_blocks(selected_indices); engine build inside the bracket"}
+            "path": ("EngineViT(weights).to(device) -> Auto2SSPInterface.fit() (ONE walk over one loader: the search's baseline carries the stage-1 hook)"
+                     if evalb is None else "EngineViT(weights).to(device) -> Auto2SSPInterface (deferred att + mlp importances, two loaders)")
+                    + " -> prune_vit_mlp_width(precomputed_importance) -> prune_vit_attention_blocks(selected_indices); engine build inside the bracket"}
 
 
 def main():

@@ -10,7 +10,7 @@ w = synthetic_weights("vit_base_patch16_224", classes=1000, seed=0, std=0.02, ep
 plan = plan_from_stats(stats_from_shapes(768, 12, 3072, 1000, 197, 16), 0.375, min_remaining=512)
 g = torch.Generator(device=dev).manual_seed(1)
 calib = [{"pixel_values": torch.randn(64, 3, 224, 224, generator=g, device=dev)} for _ in range(8)]
-evalb = [{"pixel_values": torch.randn(64, 3, 224, 224, generator=g, device=dev), "labels": torch.randint(0, 1000, (64,), generator=g, device=dev)} for _ in range(5)]
+unused_evalb = [{"pixel_values": torch.randn(64, 3, 224, 224, generator=g, device=dev), "labels": torch.randint(0, 1000, (64,), generator=g, device=dev)} for _ in range(5)]
 T = {}
 orig_init = E.VitEngine.__init__
 def timed_init(self, *a, **k):
@@ -19,16 +19,24 @@ def timed_init(self, *a, **k):
 E.VitEngine.__init__ = timed_init
 def lap(name, t0):
     torch.cuda.synchronize(); T.setdefault(name, []).append(time.perf_counter() - t0); return time.perf_counter()
+def teacher(px):
+    m = EngineViT(w).to(dev)
+    with torch.no_grad():
+        lb = m(px).argmax(-1)
+    vp.release_engines()
+    return lb
+for b in calib[:5]:                 # round 5: ONE loader, its first five batches carry labels (the search evaluates them)
+    b["labels"] = teacher(b["pixel_values"])
+orig_pp = vp._core.prune_pass
+def timed_pp(*a, **k):
+    t = time.perf_counter(); r = orig_pp(*a, **k); T.setdefault("prune_pass host (enqueue everything)", []).append(time.perf_counter() - t); return r
+vp._core.prune_pass = timed_pp
 for it in range(4):
     model = EngineViT(w).to(dev); torch.cuda.synchronize()
     T_it0 = t = time.perf_counter()
-    s2 = Auto2SSPInterface(model, evalb, device=dev, importance_mode="copy", batch_limit=len(evalb), min_remaining=512)
-    s1 = Auto2SSPInterface(model, calib, device=dev, batch_limit=None, min_remaining=512)
-    t = lap("ifaces", t)
-    att_fin = s2._att_importance_deferred(); t = lap("att_enqueue(+engine)", t)
-    mlp_fin = s1._mlp_importance_deferred(); t = lap("mlp_enqueue", t)
-    att, mlp = att_fin(), mlp_fin(); t = lap("await", t)
-    res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[plan.per_block_neurons_to_prune] * 12, min_remaining=512, strategy="l1", collect_masks=True, precomputed_importance=[x.to(torch.float32) for x in mlp]); t = lap("width", t)
+    iface = Auto2SSPInterface(model, calib, device=dev, importance_mode="copy", batch_limit=5, min_remaining=512, score_batch_limit=None)
+    att, mlp = iface.fit(); t = lap("fit (engine build + one pass + wait)", t)
+    res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[plan.per_block_neurons_to_prune] * 12, min_remaining=512, strategy="l1", collect_masks=True, precomputed_importance=[x.to(torch.float32) for x in mlp]); t = lap("width (host mask step + 36 gathers)", t)
     out = vp.prune_vit_attention_blocks(res["model"], sparsity=5 / 12, dataloader=None, device=dev, num_to_prune=5, show_progress=False, selected_indices=[int(i) for i in torch.argsort(att)[:5]]); t = lap("depth", t)
     T.setdefault("total", []).append(time.perf_counter() - T_it0)
     vp.release_engines(); del model, res, out

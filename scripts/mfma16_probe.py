@@ -42,8 +42,13 @@ def main():
         row = {"shape": name, "M": M, "N": N, "K": K, "library (bias only)": lib}
         est = lib["sustained_us"] * 1.4
         for rnd in range(2):
-            for label, binary in (("32x32x16", "gemm_bench_nt3.bin"), ("16x16x32 (probe)", "gemm_bench_nt3_m16.bin")):
-                row[f"{label} #{rnd}"] = run(binary, M, N, K, epi, sampler, est)
+            for label, binary in (("32x32x16", "gemm_bench_nt3.bin"), ("16x16x32 (probe)", "gemm_bench_nt3_m16.bin"),
+                                  # second question: with 16-cycle MFMAs a DMA piece between two of them stalls the matrix pipe for ~(60 - 16) cycles
+                                  # instead of ~(60 - 32): do some of the unit's four pieces belong in the LOAD phase now?  (PP_NL, see gemm256.hip.h)
+                                  ("16x16x32, 1 piece in LOAD", "gemm_bench_nt3_m16_nl1.bin"), ("16x16x32, 2 pieces in LOAD", "gemm_bench_nt3_m16_nl2.bin"),
+                                  ("16x16x32, 3 pieces in LOAD", "gemm_bench_nt3_m16_nl3.bin")):
+                if os.path.exists(os.path.join(TOOLS, binary)):
+                    row[f"{label} #{rnd}"] = run(binary, M, N, K, epi, sampler, est)
         a = min(row[f"32x32x16 #{r}"].get("sustained_us", 1e9) for r in range(2))
         b = min(row[f"16x16x32 (probe) #{r}"].get("sustained_us", 1e9) for r in range(2))
         row["speedup_16x16x32"] = round(a / b, 4)

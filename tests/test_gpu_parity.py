@@ -2084,3 +2084,44 @@ def test_unsupported_geometries_fail_when_the_engine_is_created(gpu):
     finally:
         for k in ("_t_b16_384", "_t_dh32", "_t_h14_196"):
             W.VIT_CONFIGS.pop(k, None)
+
+
+def test_gelu_epilogue_on_every_bf16_value(gpu):
+    """The fc1 epilogue's erf-GELU over ALL 65 536 bf16 inputs (its whole domain), through ssp2_linear_bf16 with an identity weight so
+    that the epilogue sees exactly the value put in — both GEMM kernels — against torch's bf16 GELU on the CPU (the reference's arithmetic
+    under autocast: F.gelu of a bf16 tensor).  scripts/gelu_candidates.py (profiles/r05_i_gelu_candidates.txt) predicted from an fp32
+    emulation what is asserted here:
+      * |x| < 2 (and every x >= 0 up to 1e30): the SAME bits;
+      * the negative tail -16 <= x <= -2: torch evaluates 0.5 x (1 + erf(x / sqrt 2)) in fp32, where 1 + erf cancels — its OWN result is off
+        the correctly rounded one there; this epilogue uses erfc (no cancellation).  At most 2 bf16 ulp apart, values below 3e-3, and only
+        there may bits differ (predicted: ~210 inputs);
+      * where the result underflows (x <= -14) torch returns -0.0 and the engine +0.0: equal as numbers, counted, not an error;
+      * bf16 denormal inputs (|x| < 1e-30) and |x| >= 1e30 (0.5 x (1 + erf) overflows in torch's order of operations) are outside the
+        range an activation can take and are not compared."""
+    from ssp2vit.engine import VitEngine
+    w, _, _ = load_tiny_golden("timm")
+    eng = _engine(w, 4)
+    bits = torch.arange(65536, dtype=torch.int32)
+    x = (bits << 16).view(torch.float32)                             # every bf16 value, exactly representable in fp32
+    xb = x.to(torch.bfloat16)
+    a = xb.view(1024, 64).to(gpu)
+    ref = torch.nn.functional.gelu(xb).view(1024, 64)
+    eye = torch.eye(64)
+    for kernel in ("small", "big"):
+        out = eng.linear(a, eye, None, "gelu", kernel=kernel).cpu()
+        ax = x.abs().view(1024, 64)
+        cmp = torch.isfinite(x.view(1024, 64)) & (ax >= 1e-30) & (ax < 1e30)
+        same = out.view(torch.int16) == ref.view(torch.int16)
+        zero_sign = (~same) & (out.float() == 0) & (ref.float() == 0)
+        diff = cmp & ~same & ~zero_sign
+        where = x.view(1024, 64)[diff]
+        print(f"\n[gelu {kernel}] differing from torch's bf16 GELU: {int(diff.sum())} of {int(cmp.sum())} compared inputs, x in "
+              f"[{float(where.min()) if where.numel() else 0:.3f}, {float(where.max()) if where.numel() else 0:.3f}]; -0.0 / +0.0 only: {int((zero_sign & cmp).sum())}")
+        assert bool(((where >= -16) & (where <= -2)).all()), "bits may differ from torch only in the cancellation tail -16 <= x <= -2"
+        assert int(diff.sum()) <= 260
+        ulp = (out.view(torch.int16).int() - ref.view(torch.int16).int()).abs()[diff]
+        assert int(ulp.max()) <= 2 if ulp.numel() else True
+        assert float(ref.float().abs()[diff].max()) < 3e-3 if ulp.numel() else True
+        # NaN stays NaN, +inf -> +inf
+        assert bool(torch.isnan(out.float()[torch.isnan(x.view(1024, 64))]).all())
+        assert float(out.float()[x.view(1024, 64) == float("inf")][0]) == float("inf")
