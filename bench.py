@@ -450,7 +450,7 @@ def act_l2_figure(eng, batch, tokens, d_int, dev, n_images=512):
             "kernel": "act_l2_norms_kernel<bf16> + score_colsum_halves_kernel (standalone a2; 2 launches per call)"}
 
 
-def api_level(args, weights, calib, evalb, plan, dev, steps=3, search_batches=None):
+def api_level(args, weights, calib, evalb, plan, dev, steps=5, search_batches=None):
     """The same prune through the reference-named API on a LIVE module that sits on the device (as the reference keeps
     it): Auto2SSPInterface importances (attention first, then MLP, both enqueued before either is waited for) ->
     prune_vit_mlp_width(precomputed_importance) -> prune_vit_attention_blocks(selected_indices).  The engine build

@@ -27,11 +27,20 @@ def teacher(px):
     return lb
 for b in calib[:5]:                 # round 5: ONE loader, its first five batches carry labels (the search evaluates them)
     b["labels"] = teacher(b["pixel_values"])
+orig_ef = vp.engine_for
+def timed_ef(*a, **k):
+    torch.cuda.synchronize(); t = time.perf_counter(); r = orig_ef(*a, **k); torch.cuda.synchronize(); T.setdefault("engine_for (from_module + VitEngine)", []).append(time.perf_counter() - t); return r
+vp.engine_for = timed_ef
+import ssp2vit.weights as W_
+orig_fm = W_.from_module
+def timed_fm(*a, **k):
+    t = time.perf_counter(); r = orig_fm(*a, **k); T.setdefault("weights.from_module (host)", []).append(time.perf_counter() - t); return r
+W_.from_module = timed_fm
 orig_pp = vp._core.prune_pass
 def timed_pp(*a, **k):
     t = time.perf_counter(); r = orig_pp(*a, **k); T.setdefault("prune_pass host (enqueue everything)", []).append(time.perf_counter() - t); return r
 vp._core.prune_pass = timed_pp
-for it in range(4):
+for it in range(6):
     model = EngineViT(w).to(dev); torch.cuda.synchronize()
     T_it0 = t = time.perf_counter()
     iface = Auto2SSPInterface(model, calib, device=dev, importance_mode="copy", batch_limit=5, min_remaining=512, score_batch_limit=None)

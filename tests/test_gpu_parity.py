@@ -2093,8 +2093,8 @@ def test_gelu_epilogue_on_every_bf16_value(gpu):
     emulation what is asserted here:
       * |x| < 2 (and every x >= 0 up to 1e30): the SAME bits;
       * the negative tail -16 <= x <= -2: torch evaluates 0.5 x (1 + erf(x / sqrt 2)) in fp32, where 1 + erf cancels — its OWN result is off
-        the correctly rounded one there; this epilogue uses erfc (no cancellation).  At most 2 bf16 ulp apart, values below 3e-3, and only
-        there may bits differ (predicted: ~210 inputs);
+        the correctly rounded one there; this epilogue uses erfc (no cancellation).  At most 4e-6 apart in absolute terms on values below 1e-3,
+        and only there may bits differ (predicted: 212 inputs, all in [-13.2, -3.53]; measured 206);
       * where the result underflows (x <= -14) torch returns -0.0 and the engine +0.0: equal as numbers, counted, not an error;
       * bf16 denormal inputs (|x| < 1e-30) and |x| >= 1e30 (0.5 x (1 + erf) overflows in torch's order of operations) are outside the
         range an activation can take and are not compared."""
@@ -2119,9 +2119,11 @@ def test_gelu_epilogue_on_every_bf16_value(gpu):
               f"[{float(where.min()) if where.numel() else 0:.3f}, {float(where.max()) if where.numel() else 0:.3f}]; -0.0 / +0.0 only: {int((zero_sign & cmp).sum())}")
         assert bool(((where >= -16) & (where <= -2)).all()), "bits may differ from torch only in the cancellation tail -16 <= x <= -2"
         assert int(diff.sum()) <= 260
-        ulp = (out.view(torch.int16).int() - ref.view(torch.int16).int()).abs()[diff]
-        assert int(ulp.max()) <= 2 if ulp.numel() else True
-        assert float(ref.float().abs()[diff].max()) < 3e-3 if ulp.numel() else True
+        # (in bf16 ulps the two can be far apart deep in the tail — at x = -5.56 torch's 1 + erf has no significant bit left — so the
+        # statement is absolute: |difference| <= 4e-6 on values below 1e-3; the first hardware run, written as "<= 2 ulp", said so)
+        if int(diff.sum()):
+            assert float((out.float() - ref.float()).abs()[diff].max()) <= 4e-6
+            assert float(ref.float().abs()[diff].max()) < 1e-3
         # NaN stays NaN, +inf -> +inf
         assert bool(torch.isnan(out.float()[torch.isnan(x.view(1024, 64))]).all())
         assert float(out.float()[x.view(1024, 64) == float("inf")][0]) == float("inf")
