@@ -96,6 +96,28 @@ class VitEngine:
         if keep:
             torch.cuda.current_stream(self.device).synchronize()
 
+    def geometry_key(self):
+        """What two engines must share for one to take over the other's handle (workspace, weight storage): see `reload`."""
+        return (str(self.device), self.precision, self.lib_variant, self.img, self.patch, self.dim, self.heads, self.depth, self.classes,
+                float(self.eps), tuple(int(d) for d in self.d_int))
+
+    def reload(self, weights: Dict) -> "VitEngine":
+        """Another model of the SAME geometry into this engine: every tensor is ingested again (device-to-device rounding kernels), the
+        attention flags are reset to the new model's — handle, weight storage and the (already touched) activation workspace stay.
+        What vit_pruning's engine pool does when a sweep builds a fresh module per target: a fresh engine costs its build (2.6 ms for
+        the 13 GB layer-major workspace of ViT-B/16) plus ~3 ms of first use of fresh memory, per prune (profiles/r05_m_api_profile.txt)."""
+        if self.precision != "bf16":
+            raise Ssp2Error("reload: bf16 engines only (an fp8 engine carries quantised weight images and calibrated scales)")
+        if [int(weights[f"fc1_w.{i}"].shape[0]) for i in range(self.depth)] != [int(d) for d in self.d_int]:
+            raise Ssp2Error("reload: FFN widths differ")
+        with torch.cuda.device(self.device):
+            self._load(weights)
+            for l in range(self.depth):
+                gone = bool(weights.get(f"attn_absent.{l}", False))
+                self._check((self.lib.ssp2_drop_attention if gone else self.lib.ssp2_restore_attention)(self.h, l))
+                self.absent[l] = gone
+        return self
+
     def close(self) -> None:
         if getattr(self, "h", None):
             if getattr(self, "precision", "bf16") == "fp8":

@@ -130,11 +130,20 @@ def engine_for(model, device="cuda", max_images: int = 64, precision: Optional[s
     hit = _ENGINES.get(key)
     if hit is not None and hit[0] == fp and hit[1].max_images >= max_images:
         return hit[1]
-    if hit is not None:
-        hit[1].close()
+    if hit is not None:                                   # this module's engine is stale (weights changed, or too small): it goes to the pool,
+        _ENGINES.pop(key)                                 # where the lookup below finds it again if the geometry is still the same
+        if ENGINE_POOL_MAX > 0 and hit[1].precision == "bf16" and getattr(hit[1], "h", None):
+            _POOL.append(hit[1])
+        else:
+            hit[1].close()
     dev = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}") \
         if torch.cuda.is_available() else torch.device(device)
-    eng = VitEngine(_weights.from_module(model), device=dev, max_images=max(int(max_images), 1), precision=precision)
+    flat = _weights.from_module(model)
+    eng = _from_pool(flat, dev, max(int(max_images), 1), precision)
+    while len(_POOL) > ENGINE_POOL_MAX:
+        _POOL.pop(0).close()
+    if eng is None:
+        eng = VitEngine(flat, device=dev, max_images=max(int(max_images), 1), precision=precision)
     eng.layout = _weights.detect_layout(model)
     if precision == "fp8" and key in _FP8_SCALES and len(_FP8_SCALES[key]) == eng.depth:
         for l, sc in enumerate(_FP8_SCALES[key]):
@@ -153,10 +162,42 @@ def calibrate_fp8(model, pixel_values: torch.Tensor, device="cuda", headroom: fl
     return scales
 
 
-def release_engines() -> None:
+# Engines that `release_engines()` set free, kept for the NEXT model of the same geometry (VitEngine.reload): a sweep that builds a fresh
+# module per target (the CLI's --sparsity_rate -2, bench.py's API leg) then pays a weight ingest per prune, not an engine build plus the
+# first use of 13 GB of fresh workspace.  At most ENGINE_POOL_MAX engines wait here (each holds its workspace in HBM); 0 switches the
+# pool off (SSP2_ENGINE_POOL); `release_engines(free=True)` closes everything.
+ENGINE_POOL_MAX = int(os.environ.get("SSP2_ENGINE_POOL", "1"))
+_POOL: List[Any] = []
+
+
+def _from_pool(flat, dev, max_images: int, precision: str):
+    if precision != "bf16":
+        return None
+    for i, e in enumerate(_POOL):
+        try:
+            same = (str(e.device) == str(dev) and e.precision == precision and e.max_images >= max_images and e.lib_variant is None
+                    and (e.img, e.patch, e.dim, e.heads, e.depth, e.classes) == tuple(int(flat[k]) for k in ("img", "patch", "dim", "heads", "depth", "classes"))
+                    and abs(e.eps - float(flat.get("eps", 1e-6))) < 1e-15
+                    and [int(d) for d in e.d_int] == [int(flat[f"fc1_w.{l}"].shape[0]) for l in range(e.depth)])
+        except Exception:
+            same = False
+        if same:
+            _POOL.pop(i)
+            return e.reload(flat)
+    return None
+
+
+def release_engines(free: bool = False) -> None:
+    """The engines built for live modules are set free: closed, or — bf16 engines, up to ENGINE_POOL_MAX of them — parked for the next
+    model of the same geometry.  `free=True` closes the parked ones too."""
     for _, (_, e) in list(_ENGINES.items()):
-        e.close()
+        if not free and ENGINE_POOL_MAX > 0 and e.precision == "bf16" and getattr(e, "h", None):
+            _POOL.append(e)
+        else:
+            e.close()
     _ENGINES.clear()
+    while len(_POOL) > (0 if free else ENGINE_POOL_MAX):
+        _POOL.pop(0).close()
 
 
 def _tokens_of(model) -> int:

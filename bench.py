@@ -486,6 +486,7 @@ def api_level(args, weights, calib, evalb, plan, dev, steps=5, search_batches=No
         last = out["pruned_indices"]
         vp.release_engines()
         del model, res, out
+    vp.release_engines(free=True)
     t = sorted(times[1:])
     return {"prune_time_s": round(t[len(t) // 2], 4), "steps": steps, "all_s": [round(x, 4) for x in times[1:]],
             "selected_blocks": last,

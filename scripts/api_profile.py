@@ -45,6 +45,9 @@ for it in range(6):
     T_it0 = t = time.perf_counter()
     iface = Auto2SSPInterface(model, calib, device=dev, importance_mode="copy", batch_limit=5, min_remaining=512, score_batch_limit=None)
     att, mlp = iface.fit(); t = lap("fit (engine build + one pass + wait)", t)
+    if it >= 2:     # the same call again on the engine that now exists (outside the prune's own total): what a fresh engine costs beyond its build
+        iface.fit(); lap("fit again, cached engine (not part of total)", t)
+        T_it0 += time.perf_counter() - t; t = time.perf_counter()
     res = vp.prune_vit_mlp_width(model, n_to_prune_per_block=[plan.per_block_neurons_to_prune] * 12, min_remaining=512, strategy="l1", collect_masks=True, precomputed_importance=[x.to(torch.float32) for x in mlp]); t = lap("width (host mask step + 36 gathers)", t)
     out = vp.prune_vit_attention_blocks(res["model"], sparsity=5 / 12, dataloader=None, device=dev, num_to_prune=5, show_progress=False, selected_indices=[int(i) for i in torch.argsort(att)[:5]]); t = lap("depth", t)
     T.setdefault("total", []).append(time.perf_counter() - T_it0)

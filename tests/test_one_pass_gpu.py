@@ -188,3 +188,37 @@ def test_fit_and_the_reference_named_wrappers_take_one_pass(gpu):
     base, cand, tot = vp.depth_search_counts(model, batches, "cuda", 2)
     assert tot == 32 and torch.equal(att, torch.tensor([max(0.0, base / tot - cc / tot) for cc in cand], dtype=torch.float32))
     vp.release_engines()
+
+
+def test_engine_pool_hands_the_next_model_of_the_same_geometry_a_reloaded_engine(gpu):
+    """vit_pruning's engine pool (release_engines parks a bf16 engine; engine_for of the next module of the same geometry reloads it instead
+    of building one): the second model's results are those of an engine built for it from scratch — every weight is ingested again, the
+    attention flags are reset — and a module whose FFN widths differ gets a new engine."""
+    from ssp2vit import core, vit_pruning as vp
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.modules import EngineViT
+    from ssp2vit.weights import synthetic_weights
+    vp.release_engines(free=True)
+    g = torch.Generator().manual_seed(5)
+    batches = [{"pixel_values": torch.randn(8, 3, 224, 224, generator=g), "labels": torch.randint(0, 10, (8,), generator=g)} for _ in range(3)]
+    w1 = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=1, std=0.05, eps=1e-6, bias_std=0.02)
+    w2 = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=2, std=0.05, eps=1e-6, bias_std=0.02)
+    m1 = EngineViT(w1).to(gpu)
+    vp.prune_vit_attention_blocks(m1, 0.25, dataloader=batches, device="cuda", batch_limit=3, show_progress=False)     # m1's engine ends with dropped attention blocks
+    e1 = vp.engine_for(m1, "cuda", 8)
+    assert any(e1.absent)
+    vp.release_engines()
+    assert len(vp._POOL) == 1 and vp._POOL[0] is e1
+    m2 = EngineViT(w2).to(gpu)
+    s2, c2 = vp.importances_one_pass(m2, batches, "cuda", 3)
+    e2 = vp.engine_for(m2, "cuda", 8)
+    assert e2 is e1 and not any(e2.absent) and len(vp._POOL) == 0                        # the parked engine, reloaded and reset
+    fresh = VitEngine(w2, max_images=e2.max_images)
+    rs, rc = core.prune_pass(fresh, batches, [768] * 12, "pre_gelu", 12, score_limit=3, search_limit=3)
+    assert _same(s2, rs) and c2 == rc
+    fresh.close()
+    res = vp.prune_vit_mlp_width(m2, n_to_prune_per_block=[100] * 12, min_remaining=256, strategy="l1")          # other widths: the pooled geometry no longer fits
+    e3 = vp.engine_for(m2, "cuda", 8)
+    assert e3 is not e2 and e3.d_int == [668] * 12
+    vp.release_engines(free=True)
+    assert len(vp._POOL) == 0
