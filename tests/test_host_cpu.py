@@ -496,6 +496,11 @@ def test_bench_self_launch_two_ranks_relays_rank0_line_and_failures():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launcher"], capture_output=True,
                          text=True, timeout=300, env=dict(env, SSP2_SELFTEST_FAIL_RANK="1"))
     assert bad.returncode != 0
+    # the driver's widest case: eight ranks started by `--gpus 8` itself (gloo, no GPU)
+    out8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--selftest-launcher"], capture_output=True,
+                          text=True, timeout=600, env=env)
+    assert out8.returncode == 0, out8.stdout + out8.stderr
+    assert [json.loads(l) for l in out8.stdout.splitlines() if l.startswith("{")] == [{"metric": "launcher_selftest", "n_gpus": 8, "cuda_initialised": False}]
 
 
 # ------------------------------------------------------------------------------------------ CLI --weights / --gpus

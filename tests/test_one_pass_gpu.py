@@ -204,8 +204,9 @@ def test_engine_pool_hands_the_next_model_of_the_same_geometry_a_reloaded_engine
     w1 = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=1, std=0.05, eps=1e-6, bias_std=0.02)
     w2 = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=2, std=0.05, eps=1e-6, bias_std=0.02)
     m1 = EngineViT(w1).to(gpu)
-    vp.prune_vit_attention_blocks(m1, 0.25, dataloader=batches, device="cuda", batch_limit=3, show_progress=False)     # m1's engine ends with dropped attention blocks
+    vp.importances_one_pass(m1, batches, "cuda", 3)                                      # builds m1's engine with the layer-major workspace
     e1 = vp.engine_for(m1, "cuda", 8)
+    e1.drop_attention([2, 5])                                                            # ... which ends its life with two blocks bypassed
     assert any(e1.absent)
     vp.release_engines()
     assert len(vp._POOL) == 1 and vp._POOL[0] is e1
