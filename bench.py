@@ -856,7 +856,11 @@ def main():
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
                                 "flops_per_launch_avg": prof.flops / prof.launches,
                                 "library_yardstick": library_yardstick("fc1") if args.precision == "bf16" and args.model == "vit_base_patch16_224" else None,
-                                "shapes": f"[{eng.rows(min(n_calib, calib_chunk), args.batch)} | {eval_chunk * tokens} | {eval_chunk}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk{lm} | CLS tail)"}
+                                "shapes": (f"[{core.slab_rows(tokens, max(1, eval_chunk // args.batch) * args.batch, args.batch)} hooked | the same x 0..{depth - 2} unhooked | "
+                                           f"{eng.rows(max(n_calib - n_eval, args.batch), args.batch) if n_calib > n_eval else 0} | {eval_chunk}] x {d_int} x {dim} (the search chunk's baseline in {args.batch}-image slabs, "
+                                           f"carrying the stage-1 hook | the candidates under way in the same launch sequence | scores-only launch of the calibration batches the search does not take | CLS tail)"
+                                           if one_pass else
+                                           f"[{eng.rows(min(n_calib, calib_chunk), args.batch)} | {eval_chunk * tokens} | {eval_chunk}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk{lm} | CLS tail)")}
         if args.precision == "fp8":
             line["fp8_saturation_events"] = eng.fp8_saturation()       # waves that clipped an attention output at the e4m3 range (0 = none)
         if families is not None:
