@@ -348,9 +348,15 @@ def build_argparser():
 def main(argv=None):
     args = build_argparser().parse_args(argv)
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))   # RCCL
+        if os.environ.get("SSP2_REHEARSE_ONE_CARD") == "1":
+            # a correctness rehearsal of the N-rank job on a one-GPU box (as bench.py's): every rank computes on cuda:0 and the exchanges go over
+            # gloo (RCCL refuses two ranks on one device; the collectives are the same calls, their tensors take dist.device_for_backend's host route)
+            torch.cuda.set_device(0)
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))   # RCCL
     rate = args.sparsity_rate if args.sparsity_rate is not None else args.target
     targets = [0.25, 0.375, 0.5] if rate == -2 else [rate]
     if args.stage == "both" and any(t is None for t in targets):

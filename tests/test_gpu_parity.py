@@ -2128,3 +2128,38 @@ def test_gelu_epilogue_on_every_bf16_value(gpu):
         # is poisoned either way; -inf is NaN in both.)
         assert bool(torch.isnan(out.float()[torch.isnan(x.view(1024, 64))]).all())
         assert bool(torch.isnan(out.float()[torch.isinf(x.view(1024, 64))]).all())
+
+
+@pytest.mark.timeout(900)
+def test_cli_two_ranks_on_local_data_equal_one_rank(gpu, tmp_path):
+    """The CLI end to end at TWO ranks (`--gpus 2`: it starts its own ranks; SSP2_REHEARSE_ONE_CARD=1: both compute on this card, the
+    exchanges go over gloo) on LOCAL uint8 data — sharded loaders, a GLOBAL --eval-batches limit (it used to count per rank),
+    the one-pass prune, the apply — against the same command at one rank: the same masks, the same pruned blocks, the same accuracies.
+    240 calibration images (4 batches: two per rank), --eval-batches 3 (the search takes global batches 0, 1, 2: rank 0 two, rank 1 one)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import PKG
+    rng = np.random.default_rng(11)
+    np.savez(tmp_path / "calib.npz", images=rng.integers(0, 256, size=(240, 32, 32, 3), dtype=np.uint8), labels=rng.integers(0, 10, size=240))
+    np.savez(tmp_path / "eval.npz", images=rng.integers(0, 256, size=(160, 32, 32, 3), dtype=np.uint8), labels=rng.integers(0, 10, size=160))
+    reps = {}
+    for n in (1, 2):
+        out = tmp_path / f"run{n}"
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+        env["SSP2_REHEARSE_ONE_CARD"] = "1"
+        p = subprocess.run([sys.executable, os.path.join(PKG, "auto_2ssp.py"), "--gpus", str(n), "--model", "vit_tiny_patch16_224", "--target", "0.3",
+                            "--eval-batches", "3", "--num-classes", "10", "--min-remaining", "256", "--calib-data", str(tmp_path / "calib.npz"),
+                            "--eval-data", str(tmp_path / "eval.npz"), "--output-dir", str(out)], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        rj = [f for f in os.listdir(out / "reports") if f.endswith(".json")]
+        assert len(rj) == 1                                            # rank 0 writes, once
+        reps[n] = json.load(open(out / "reports" / rj[0]))
+    a, b = reps[1], reps[2]
+    assert b["config"]["gpus"] == 2 and a["config"]["gpus"] == 1
+    assert a["artifacts"]["pruned_block_indices"] == b["artifacts"]["pruned_block_indices"]
+    ma = json.load(open(a["artifacts"]["ffn_prune_masks_path"]))["ffn_masks"]
+    mb = json.load(open(b["artifacts"]["ffn_prune_masks_path"]))["ffn_masks"]
+    assert ma == mb
+    for k in ("acc_baseline", "acc_stage1", "acc_stage2", "params_after_stage2"):
+        assert a["metrics"][k] == b["metrics"][k], k
