@@ -732,6 +732,11 @@ def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int,
         in_search = search_limit is None or gi < int(search_limit)
         in_score = score_limit is None or gi < int(score_limit)
         eng = state["eng"] or resolve(n)
+        if callable(engine) and n > eng.max_images:       # a batch larger than everything seen so far: what is open runs on the old engine, then a larger one
+            flush_fused(); flush_s1(); run_pending()
+            counts_so_far = state["counts"]
+            eng = resolve(n)
+            state["counts"] = counts_so_far.to(eng.device)
         PASS_STATS["score_batches_owned"] += int(in_score); PASS_STATS["search_batches_owned"] += int(in_search)
         if in_search:
             if "labels" not in batch:
