@@ -96,6 +96,7 @@ def layer_major_images(engine, slots: int, n: int, device=None) -> int:
 
 
 _COPY_STREAMS = {}
+_COUNT_STREAMS = {}
 _INDEX_CACHE = {}
 
 
@@ -264,8 +265,28 @@ def _reduce_scores(local, n_batches: int, n_samples: int, d_ints: Sequence[int],
     (reference src/vit_pruning.py:154-157, :194-200).  n_batches / n_samples: what this rank saw (see _OwnedBatches)."""
     rank, ws = _dist.world(process_group)
     if sharded and (ws > 1 or (_dist.FORCE_COLLECTIVES and _dist._initialised())):
-        tot = torch.tensor([n_batches, n_samples], dtype=torch.int64, device=_dist._default_device(process_group))
-        n_batches, n_samples = (int(v) for v in _dist.all_reduce_counts(tot, process_group).to("cpu"))
+        dev = _dist._default_device(process_group)
+        if dev.type == "cuda":
+            # The global batch / sample counts must come BACK to the host (they size the exchange below).  On the compute stream that
+            # read-back would wait for everything already enqueued — in the one-pass prune the whole search — before the exchange, the
+            # scores' copy and the tails could even be enqueued.  The two integers have no producer on the device, so their little
+            # all-reduce runs on a side stream of its own and the host waits for that stream only.
+            key = dev.index if dev.index is not None else torch.cuda.current_device()
+            ent = _COUNT_STREAMS.get(key)
+            if ent is None:             # (stream, pinned host pair, device pair): made once per device
+                ent = _COUNT_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.zeros(2, dtype=torch.int64).pin_memory(),
+                                             torch.zeros(2, dtype=torch.int64, device=dev))
+            side, pin, tot = ent
+            pin[0], pin[1] = int(n_batches), int(n_samples)
+            with torch.cuda.stream(side):
+                tot.copy_(pin, non_blocking=True)
+                _dist.all_reduce_counts(tot, process_group)
+                pin.copy_(tot, non_blocking=True)
+                side.synchronize()
+            n_batches, n_samples = int(pin[0]), int(pin[1])
+        else:
+            tot = torch.tensor([n_batches, n_samples], dtype=torch.int64, device=dev)
+            n_batches, n_samples = (int(v) for v in _dist.all_reduce_counts(tot, process_group).to("cpu"))
     ld = max((int(d) + 63) // 64 * 64 for d in d_ints) if d_ints else 0          # = VitEngine.score_ld
     vecs = _dist.gather_batch_vectors(local, n_batches, process_group,
                                       shape=(local[0][1].shape if local else (len(d_ints), ld)))
