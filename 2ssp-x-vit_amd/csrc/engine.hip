@@ -128,6 +128,7 @@ struct ssp2_engine {
   int n_xcc_seen = 0;
   bool xcc_ok = false;                         // XCC_ID probe at create: ids 0..7 seen, nothing else (else the fused form stays off)
   unsigned int* fp8_sat = nullptr;             // device counter of clipped e4m3 casts (SSP2_Q_FP8_SATURATED)
+  unsigned long long* act8_top = nullptr;      // fp8 calibration: e4m3 bytes of the fc1 -> fc2 hand-off found ON the top code (SSP2_Q_FP8_FC2_TOP_CODES)
   unsigned int* attn_amax = nullptr;           // fp8 calibration: [depth] float bits of max |attention output| per block (ssp2_fp8_calibrate_*)
   bool fp8_calibrating = false;
   uint8_t* obuf8 = nullptr;                    // attention output as e4m3(o * 16) bytes: the A operand of the fp8 out-projection (SSP2_OPT_FP8_PROJ)
@@ -632,6 +633,7 @@ int ssp2_fp8_calibrate_begin(ssp2_handle e) {
   if (!e) return fail(SSP2_EINVAL, "null handle");
   if (!e->fp8 || !e->attn_amax) return fail(SSP2_ESTATE, "fp8 calibration needs ssp2_set_precision(h, SSP2_PREC_FP8) first");
   HIPCHK(hipMemsetAsync(e->attn_amax, 0, (size_t)e->d.depth * 4, e->stream));
+  if (e->act8_top) HIPCHK(hipMemsetAsync(e->act8_top, 0, 8, e->stream));
   e->fp8_calibrating = true;
   return 0;
 }
@@ -700,6 +702,12 @@ int ssp2_query(ssp2_handle e, int what) {
     case SSP2_Q_MAX_IMAGES: return e->d.max_images;
     case SSP2_Q_TOKENS: return e->tokens;
     case SSP2_Q_IMG: return e->d.img;
+    case SSP2_Q_FP8_FC2_TOP_CODES: {
+      if (!e->act8_top) return 0;
+      unsigned long long v = 0;
+      if (hipStreamSynchronize(e->stream) != hipSuccess || hipMemcpy(&v, e->act8_top, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(SSP2_EHIP, "reading the top-code counter failed");
+      return (int)std::min<unsigned long long>(v, 0x7fffffffull);
+    }
     case SSP2_Q_LAB_BUILD:
 #ifdef SSP2_LAB
       return 1;
@@ -846,6 +854,7 @@ int ssp2_set_precision(ssp2_handle e, int mode) {
     if ((rc = dalloc(e, &e->obuf8, (size_t)e->rows_cap * e->ld8_dim, true))) return rc;
     if ((rc = dalloc(e, &e->fp8_sat, 4, true))) return rc;                   // (zeroed by dalloc)
     if ((rc = dalloc(e, &e->attn_amax, (size_t)e->d.depth, true))) return rc;
+    if ((rc = dalloc(e, &e->act8_top, (size_t)1, true))) return rc;
   }
   e->fp8 = true;
   return 0;
@@ -1057,6 +1066,11 @@ int ssp2_layers_prefix(ssp2_handle e, const float* x_in, float* x, int n, int l_
       rc = run_fc1(f);
     }
     if (rc) return rc;
+    if (f8_mlp && e->fp8_calibrating && e->act8_top) {       // calibration pass: how much of the GELU output did the saturating e4m3 cast put on its top code?
+      ProfScope ps(e, SSP2_K_OTHER);
+      hipLaunchKernelGGL(e4m3_top_code_count_kernel, dim3(1024), dim3(256), 0, e->stream, e->act8, (long)M, ceil_to(L.d_int, 16), ld8_int, e->act8_top);
+      HIPCHK(hipGetLastError());
+    }
     if (score_site) {
       float* row = batch_scores + (size_t)l * score_ld;
       if (fused) {

@@ -400,6 +400,27 @@ __global__ __launch_bounds__(256) void quant_rows_e4m3_kernel(const bf16* __rest
   if (lane == 0) scale[row] = sc;
 }
 
+// fp8 calibration (ssp2_fp8_calibrate_*): how many e4m3 bytes of the fc1 -> fc2 hand-off [rows, cols] (leading dimension ld bytes) sit ON the
+// top code (+-448, 0x7e / 0xfe) — what the saturating cast of the GELU output writes for every value at or beyond the e4m3 range.  The fc1
+// epilogue cannot count them itself (no register left: 253 VGPRs); a calibration pass can afford one more read of the activation.
+__global__ void e4m3_top_code_count_kernel(const uint8_t* __restrict__ a, long rows, int cols, int ld, unsigned long long* __restrict__ count) {
+  unsigned int c = 0;
+  const int c16 = cols / 16;
+  const long n16 = rows * c16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c16; const int k = (int)(i - r * c16);
+    const i32x4 v = *(const i32x4*)(a + r * ld + k * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned int w = (unsigned int)v[j] & 0x7f7f7f7fu;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) c += ((w >> (8 * b)) & 0xffu) == 0x7eu;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+
 // ------------------------------------------------------------------------------------------------
 // fp8 calibration (ssp2_fp8_calibrate_*): largest |value| of a bf16 matrix [rows, cols] (leading dimension ld) -> atomicMax on the bits of
 // a non-negative float (*amax_bits; non-negative floats order as unsigned integers).

@@ -191,7 +191,20 @@ class VitEngine:
                 self.layers(x, chunk.shape[0], 0, self.depth)
         finally:
             self._check(self.lib.ssp2_fp8_calibrate_end(self.h, float(headroom)))
+        top = self.fp8_fc2_top_codes()
+        if top > 0:
+            import warnings
+            warnings.warn(f"ssp2vit fp8 calibration: {top} FFN activation value(s) of the calibration images sit on the e4m3 top code (|GELU output| >= 448): "
+                          "the fc1 -> fc2 hand-off of this checkpoint clips in fp8 mode; use precision='bf16'", RuntimeWarning, stacklevel=2)
         return [float(self.lib.ssp2_fp8_attn_scale(self.h, l)) for l in range(self.depth)]
+
+    def fp8_fc2_top_codes(self) -> int:
+        """fp8 mode: how many e4m3 bytes of the fc1 -> fc2 hand-off the LAST calibration pass (calibrate_fp8) found on the top code +-448 — GELU
+        outputs at or beyond the e4m3 range, which the saturating cast clips (SSP2_Q_FP8_FC2_TOP_CODES).  0: that hand-off is safe on those images."""
+        v = self.lib.ssp2_query(self.h, 9)
+        if v < 0:
+            self._check(v)
+        return int(v)
 
     def fp8_saturation(self, reset: bool = False) -> int:
         """fp8 mode: how many waves have CLIPPED a value when the attention output was handed to the out-projection as e4m3(o x 16)

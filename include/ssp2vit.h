@@ -276,10 +276,15 @@ int ssp2_profile_end(ssp2_handle h, double* total_ms, int64_t* launches, double*
  * out-projection — it is written as e4m3(o x 16), so |o| > 28 clips — since the handle was created or the counter was last read with
  * SSP2_Q_FP8_SATURATED_RESET (which returns the count and zeroes it).  Synchronises the handle's stream.  0 on a model whose
  * attention outputs stay in range; > 0 means: run that checkpoint with SSP2_OPT_FP8_PROJ = 0 (or in bf16).  (The LayerNorm outputs
- * carry per-row scales and cannot clip; the GELU output that fc2 reads is cast unscaled and NOT counted — it clips beyond 448, and
- * counting in that epilogue costs the fc1 kernels the registers they do not have: 20-188 spilled bytes per lane when it was tried.) */
+ * carry per-row scales and cannot clip; the GELU output that fc2 reads is cast unscaled — it clips beyond 448; counting in that epilogue
+ * costs the fc1 kernels the registers they do not have (20-188 spilled bytes per lane when it was tried), so it is counted during CALIBRATION
+ * passes instead: SSP2_Q_FP8_FC2_TOP_CODES.) */
 enum { SSP2_Q_DIM = 0, SSP2_Q_DEPTH, SSP2_Q_CLASSES, SSP2_Q_SCORE_LD /* max ceil64(d_int) */, SSP2_Q_MAX_IMAGES, SSP2_Q_TOKENS, SSP2_Q_IMG,
        SSP2_Q_FP8_SATURATED, SSP2_Q_FP8_SATURATED_RESET,
+       SSP2_Q_FP8_FC2_TOP_CODES /* fp8 mode: e4m3 bytes of the fc1 -> fc2 hand-off (the GELU output, cast unscaled and saturating) that the forwards between
+                                 * ssp2_fp8_calibrate_begin and _end found ON the top code +-448 — values at or beyond the e4m3 range.  Counted by one more read of
+                                 * the activation per block during calibration passes only (the fc1 epilogue has no register left to count in: 253 VGPRs); 0 on a
+                                 * checkpoint whose FFN activations stay below 448; > 0 says: run it in bf16.  Saturates at 2^31 - 1. */,
        SSP2_Q_LAB_BUILD /* 1: this library was built with -DSSP2_LAB (carries the opt-in kernel forms SSP2_OPT_LN_FUSION / _DEFER_RESID / _GROUP256); 0: the product build */ };
 int ssp2_query(ssp2_handle h, int what);                                  /* >= 0, or SSP2_EINVAL */
 int ssp2_tokens(ssp2_handle h);

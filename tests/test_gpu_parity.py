@@ -1719,11 +1719,11 @@ def test_layernorm_fused_behind_the_residual_gemms_gives_the_standalone_kernels_
     from ssp2vit._lib import Ssp2Error
     with pytest.raises(Ssp2Error):
         prod.set_option("ln_fusion", 1)                                 # the product build refuses what it does not instantiate
-    assert prod.lib.ssp2_query(prod.h, 9) == 0                          # SSP2_Q_LAB_BUILD
+    assert prod.lib.ssp2_query(prod.h, 10) == 0                         # SSP2_Q_LAB_BUILD
     plain = run(prod)
     prod.close()
     eng = VitEngine(w, max_images=n_img, precision=precision, lib_variant="lab")
-    assert eng.lib.ssp2_query(eng.h, 9) == 1
+    assert eng.lib.ssp2_query(eng.h, 10) == 1
     eng.set_option("ln_fusion", 0)
     for a, b in zip(plain, run()):                                      # the lab build with the switch off: the product's bits
         assert torch.equal(a, b)
@@ -2163,3 +2163,38 @@ def test_cli_two_ranks_on_local_data_equal_one_rank(gpu, tmp_path):
     assert ma == mb
     for k in ("acc_baseline", "acc_stage1", "acc_stage2", "params_after_stage2"):
         assert a["metrics"][k] == b["metrics"][k], k
+
+
+def test_fp8_fc1_to_fc2_hand_off_clipping_is_counted_by_a_calibration_pass(gpu):
+    """in fp8 mode the GELU output reaches fc2 as an UNSCALED saturating e4m3 cast — |value| >= 448 clips, and the fc1
+    epilogue has no register left to count in.  A calibration pass (VitEngine.calibrate_fp8 / ssp2_fp8_calibrate_*) now reads every block's
+    e4m3 activation once more and counts the bytes on the top code (SSP2_Q_FP8_FC2_TOP_CODES): 0 on ordinary weights; > 0 — with a
+    RuntimeWarning naming the remedy — on a model with a few huge FFN neurons; the count is exactly the number of (row, neuron) pairs whose
+    bf16-engine activation reaches 448."""
+    import warnings
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    cfg = "vit_base_patch16_224_d3"
+    w = synthetic_weights(cfg, classes=10, seed=8, std=0.03, eps=1e-6, bias_std=0.02, spread=4.0)
+    g = torch.Generator().manual_seed(4)
+    px = torch.randn(32, 3, 224, 224, generator=g).to(gpu)                      # 6304 rows: the e4m3 path (>= 4096)
+    f8 = VitEngine(w, max_images=32, precision="fp8")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        f8.calibrate_fp8(px)
+    assert f8.fp8_fc2_top_codes() == 0 and not any("top code" in str(r.message) for r in rec)
+    f8.close()
+    big = dict(w)
+    b1 = w["fc1_b.1"].clone(); b1[5] = 600.0; b1[77] = 1000.0; b1[300] = -900.0   # two neurons of block 1 far beyond 448 on every row, one far below (GELU -> 0)
+    big["fc1_b.1"] = b1
+    f8 = VitEngine(big, max_images=32, precision="fp8")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        f8.calibrate_fp8(px)
+    n = f8.fp8_fc2_top_codes()
+    print(f"\n[fp8 fc1->fc2] top-code bytes found by the calibration pass: {n} (two saturated neurons x {32 * 197} rows = {2 * 32 * 197})")
+    assert n == 2 * 32 * 197
+    assert any("top code" in str(r.message) and "bf16" in str(r.message) for r in rec)
+    f8.calibrate_fp8(px[:24])                                                    # the counter belongs to the LAST calibration pass (24 x 197 = 4728 rows)
+    assert f8.fp8_fc2_top_codes() == 2 * 24 * 197
+    f8.close()
