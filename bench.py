@@ -532,8 +532,10 @@ def main():
                     help="run stage 1 and a share of the search candidates on a second HIP stream with its own engine "
                          "workspace (per-launch durations then include the share of the machine lent to the other stream, "
                          "so the roofline object is not a clean kernel figure)")
-    ap.add_argument("--no-overlap-figure", action="store_true",
-                    help="skip the secondary two-stream figure (profiled runs: its kernels would be counted with the step's)")
+    ap.add_argument("--no-overlap-figure", action="store_true", help="(accepted; the secondary two-stream figure is opt-in since round 5: --overlap-figure)")
+    ap.add_argument("--overlap-figure", action="store_true",
+                    help="also time the round-4 form with stage 1 on a second HIP stream beside the search (two passes; slower than the one-pass default "
+                         "since round 5: 100.4 against 93.5 ms) and attach it as `stage1_beside_search`")
     ap.add_argument("--two-pass", action="store_true",
                     help="rounds 1-4: stage 1 and the depth search as two independent passes over DISJOINT calibration / evaluation sets. "
                          "Default: the reference's one-loader semantics (mask_conjunction.py:276-281, :327) — the evaluation batches are the "
@@ -782,7 +784,7 @@ def main():
     # the two stages are independent.  Not the headline: kernels of two streams share the CUs, so per-launch durations (the
     # roofline object) are not clean kernel figures in such a run.
     overlap = None
-    if world == 1 and args.config == 1 and not second and not args.no_roofline and not args.no_overlap_figure:
+    if world == 1 and args.config == 1 and not second and not args.no_roofline and args.overlap_figure and not args.no_overlap_figure:
         e2 = VitEngine(weights, device=dev, max_images=max(args.batch, calib_chunk), precision=args.precision)
         st2 = torch.cuda.Stream(dev)
         step(e2, st2, False); sync_all()
