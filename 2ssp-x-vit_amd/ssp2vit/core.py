@@ -671,7 +671,7 @@ def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int,
         PASS_STATS[k_] = 0
     local: List[Tuple[int, torch.Tensor]] = []
     seen_score = [0, 0]                      # batches / samples this rank SAW inside the score limit
-    state = {"eng": None, "counts": None, "total": 0, "s1": None, "lm_ok": False}
+    state = {"eng": None, "counts": None, "total": 0, "s1": None, "tails": None}
     fused: List[Tuple[int, torch.Tensor, torch.Tensor, bool]] = []      # (global index, pixels, labels, scored?) of the open search chunk
 
     def resolve(n: int):
@@ -702,7 +702,7 @@ def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int,
         return eng.max_images * eng.tokens + 16 * 256 >= slots * slab_rows(eng.tokens, n, g)
 
     def run_pending():          # the CLS-only tails of the previous scored chunk (held back so that its scores could leave first)
-        t, state["tails"] = state.get("tails"), None
+        t, state["tails"] = state["tails"], None
         if t is not None:
             t()
 
