@@ -800,6 +800,37 @@ def impacts_from_counts(base: int, cand: Sequence[int], total: int) -> List[floa
     return [max(0.0, baseline - float(c / max(1, total))) for c in cand]
 
 
+_MASK_POOL = None
+MASK_THREADS = os.environ.get("SSP2_MASK_THREADS", "1") != "0"       # 0: the blocks' mask steps one after the other (same results; for A/B runs)
+
+
+def mask_pool():
+    """Four worker threads, started once per process: the a7 mask step of the blocks is independent host work (torch releases the
+    interpreter lock inside argsort / sort), and starting threads costs more than the step itself."""
+    global _MASK_POOL
+    if _MASK_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _MASK_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="ssp2-mask")
+    return _MASK_POOL
+
+
+def cut_masks(imps: Sequence[torch.Tensor], n_prune: Sequence[int]) -> List[torch.Tensor]:
+    """The a7 mask step (reference src/vit_pruning.py:286-295) of every block: keep = sort(argsort(imp, descending)[:d_int - t]), int16 mask with
+    1 = prune — the same torch calls on the same 1-D tensors, blocks side by side on the mask pool (12 x 0.2 ms in a row were 2.5 ms of host time
+    at the end of a prune, more than the CLS-only tails they are meant to hide behind)."""
+    def one(args):
+        imp, t = args
+        width = imp.numel()
+        keep, _ = torch.sort(torch.argsort(imp, descending=True)[: width - int(t)])
+        m = torch.ones(width, dtype=torch.int16)
+        m[keep] = 0
+        return m
+    work = list(zip(imps, n_prune))
+    if len(work) >= 4 and MASK_THREADS and all(i.device.type == "cpu" for i in imps):
+        return list(mask_pool().map(one, work))
+    return [one(w_) for w_ in work]
+
+
 def select_for_targets(imps: Sequence[torch.Tensor], impact: torch.Tensor, plans: Sequence, min_remaining: int = 256,
                        site: Optional[str] = None) -> List[dict]:
     """The host half of a prune for one or several targets from ONE stage-1 pass and ONE search (BASELINE configs[2]:
@@ -813,14 +844,7 @@ def select_for_targets(imps: Sequence[torch.Tensor], impact: torch.Tensor, plans
     out = []
     for p in plans:
         t = int(p.per_block_neurons_to_prune)
-        masks = []
-        for imp in imps:
-            width = imp.numel()
-            tb = max(0, min(t, width - int(min_remaining)))          # reference :279-281
-            keep, _ = torch.sort(torch.argsort(imp, descending=True)[: width - tb])
-            m = torch.ones(width, dtype=torch.int16)
-            m[keep] = 0
-            masks.append(m)
+        masks = cut_masks(imps, [max(0, min(t, imp.numel() - int(min_remaining))) for imp in imps])          # reference :279-281 (the clamp), :286-295
         blocks = sorted(int(i) for i in torch.argsort(impact)[: int(p.blocks_to_prune)])
         out.append({"target": float(p.target_sparsity), "masks": masks, "blocks": blocks,
                     "mask_parity": mask_parity_report(imps, [t] * len(imps), min_remaining=int(min_remaining), site=site)})

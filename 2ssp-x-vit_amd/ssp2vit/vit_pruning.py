@@ -331,7 +331,7 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
     # host importances: the blocks are independent and torch releases the interpreter lock inside each call, so a few threads
     # cut them side by side (12 x ~0.26 ms in a row were 3 ms of the prune bracket of the reference-named API); order and results unchanged
     if len(work) >= 4 and all(w_[1].device.type == "cpu" for w_ in work):
-        done = list(_mask_pool().map(cut, work))
+        done = list(_core.mask_pool().map(cut, work))
     else:
         done = [cut(w_) for w_ in work]
     for b, keep, mask_list, idx_list in done:
@@ -366,18 +366,6 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
         return _WidthPruneResult({"model": vit_model, "ffn_pruned_indices": all_idx, "ffn_prune_masks": all_masks},
                                  lambda: mask_parity_report(used_scores, used_drop, min_remaining=0, site=site_now))
     return vit_model
-
-
-_MASK_POOL = None
-
-
-def _mask_pool():
-    """Four worker threads, started once per process (starting them costs more than the mask step they run)."""
-    global _MASK_POOL
-    if _MASK_POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _MASK_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="ssp2-mask")
-    return _MASK_POOL
 
 
 class _WidthPruneResult(dict):
