@@ -159,6 +159,8 @@ def build_tool(name: str, defines=(), out: Optional[str] = None) -> str:
     content hash of the tool's source, EVERY kernel header of csrc/ (the kernels under test live there) and the
     defines — never by file times, which do not survive the copy to a GPU box."""
     import hashlib
+    if not any(d.startswith("-DSSP2_LAB") for d in defines):
+        defines = ("-DSSP2_LAB=1", *defines)             # the micro-benchmarks exercise the lab forms too (gemm_bench epi 15, GEMM_SUSTAIN of the deferred residual)
     src = os.path.join(TOOLS, name + ".hip")
     exe = os.path.join(TOOLS, (out or name) + ".bin")
     h = hashlib.sha256(_source_hash().encode())
@@ -173,8 +175,6 @@ def build_tool(name: str, defines=(), out: Optional[str] = None) -> str:
     if os.path.exists(exe) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return exe
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not any(d.startswith("-DSSP2_LAB") for d in defines):
-        defines = ("-DSSP2_LAB=1", *defines)             # the micro-benchmarks exercise the lab forms too (gemm_bench epi 15, GEMM_SUSTAIN of the deferred residual)
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", *defines, src, "-o", exe],
                    check=True, cwd=TOOLS, timeout=900)
     with open(stamp, "w") as f:
