@@ -159,7 +159,7 @@ def build_tool(name: str, defines=(), out: Optional[str] = None) -> str:
     content hash of the tool's source, EVERY kernel header of csrc/ (the kernels under test live there) and the
     defines — never by file times, which do not survive the copy to a GPU box."""
     import hashlib
-    if not any(d.startswith("-DSSP2_LAB") for d in defines):
+    if not any(d.startswith(("-DSSP2_LAB", "-USSP2_LAB")) for d in defines):     # ("-USSP2_LAB": a tool binary with the PRODUCT's kernel forms)
         defines = ("-DSSP2_LAB=1", *defines)             # the micro-benchmarks exercise the lab forms too (gemm_bench epi 15, GEMM_SUSTAIN of the deferred residual)
     src = os.path.join(TOOLS, name + ".hip")
     exe = os.path.join(TOOLS, (out or name) + ".bin")
