@@ -436,12 +436,15 @@ def slab_rows(tokens: int, n: int, group: int) -> int:
 
 def _search_chunk(eng, px, labels, n: int, L: int, cands: Sequence[int], removed: Sequence[int], counts_dev: torch.Tensor, *,
                   slots: int, lm: bool, group: int = 0, score=None, aux_engine=None, aux_stream=None, aux_lead: float = 0.0,
-                  defer_tail: bool = False):
+                  defer_tail: bool = False, extra_px=None):
     """One chunk of the depth search: the baseline and every candidate of `cands` over the n images `px` (a tensor or a list of
     batches); correct counts are ADDED into counts_dev ([L + 1]: candidates, then the baseline).
     `group` > 0: the streams are in the SLAB layout (one slab per dataloader batch of `group` images, n a multiple of it).
     `score` = (site, chain): the baseline is the stage-1 pass too — its fc1 launches carry the hook (slot 0 of the layer-major launch
     through ssp2_layers_prefix) and the per-batch score sums f32 [n / group, L, score_ld] are returned.
+    `extra_px` (scored layer-major chunks only): n_x more images (whole slabs of `group`) that are ONLY hooked — calibration batches the search
+    does not take.  They ride in FRONT of slot 0 in every launch of the baseline (buffer: extras | slot 0 | slot 1 ...; the hooked prefix of a
+    launch is extras + slot 0), so they need no launches of their own; their score rows come first in the returned tensor.
     Returns (scores or None, tails or None): with `defer_tail` (scored layer-major chunks) the CLS-only tails — which only the counts
     need — are handed back as a callable instead of being enqueued, so that a caller can send the finished scores on their way first."""
     cand_set, removed_set = set(cands), set(removed)
@@ -453,18 +456,33 @@ def _search_chunk(eng, px, labels, n: int, L: int, cands: Sequence[int], removed
     kw = {"score_group": g} if g > 0 else {}                      # (a stand-in engine of the CPU tests knows no layouts)
     tkw = {"group": g} if g > 0 else {}
     rows = slab_rows(eng.tokens, n, g) if g > 0 else None
-    bs = eng.new_scores(n // g) if score is not None else None
+    n_x = 0
+    if extra_px is not None:
+        n_x = sum(int(p.shape[0]) for p in extra_px) if isinstance(extra_px, (list, tuple)) else int(extra_px.shape[0])
+        if not (lm and score is not None and g > 0 and n_x % g == 0 and getattr(eng, "batch_lists", False)):
+            raise ValueError("extra (hook-only) images ride on a scored layer-major chunk, in whole slabs")
+    x0 = slab_rows(eng.tokens, n_x, g) if n_x else 0          # rows the extras take in front of slot 0
+    bs = eng.new_scores((n + n_x) // g) if score is not None else None
     xb = None
     if lm and getattr(eng, "batch_lists", False):
         # the embedding lands straight in slot 0 of the slot buffer (round 2 embedded into its own tensor and copied it over)
         rows = eng.rows(n) if rows is None else rows
-        spare = 1 if score is not None else 0                 # one more slot: where the hooked LAST block of the baseline runs out of place
-        xb = torch.empty((slots + spare) * rows, eng.dim, dtype=torch.float32, device=eng.device)
+        spare = (x0 + rows) if score is not None else 0       # behind the slots: where the hooked LAST block of the baseline (and the extras) runs out of place
+        xb = torch.empty(x0 + slots * rows + spare, eng.dim, dtype=torch.float32, device=eng.device)
         if g > 0:
             pad = rows - (eng.rows(n, g) if g < n else n * eng.tokens)      # the last slab's pad rows of every slot: finite values for the row-wise kernels
             if pad:
-                xb.view(slots + spare, rows, eng.dim)[:, rows - pad:, :].zero_()
-        x = eng.embed(px, x=xb[:rows], group=g)
+                xb[x0:x0 + slots * rows].view(slots, rows, eng.dim)[:, rows - pad:, :].zero_()
+                if x0:
+                    xb[x0 - pad:x0].zero_()
+                if spare:
+                    xb[-pad:].zero_()
+        if n_x:
+            both = (list(extra_px) if isinstance(extra_px, (list, tuple)) else [extra_px]) + (list(px) if isinstance(px, (list, tuple)) else [px])
+            eng.embed(both if BATCH_LISTS else torch.cat(both, 0), x=xb[:x0 + rows], group=g)
+            x = xb[x0:x0 + rows]
+        else:
+            x = eng.embed(px, x=xb[:rows], group=g)
     else:
         x = eng.embed(px, group=g) if g > 0 else eng.embed(px)
     if lm:
@@ -480,6 +498,7 @@ def _search_chunk(eng, px, labels, n: int, L: int, cands: Sequence[int], removed
             xb = torch.empty(slots * rows, x.shape[1], dtype=x.dtype, device=x.device)
             xb[:rows].copy_(x)
         started = []
+        s0 = xb[x0:]                                          # the slots (slot 0 first); the extras sit in xb[:x0], in front of them
         for l in range(L - 1):
             k = len(started)
             if l in cand_set:
@@ -487,22 +506,24 @@ def _search_chunk(eng, px, labels, n: int, L: int, cands: Sequence[int], removed
                 # the input of block l) into its own slot — the fc2 epilogue reads slot 0 and writes slot k + 1
                 # (ssp2_layers_from).  Round 2 copied the 194 MB stream into the slot first: 11 copies per step.
                 if OUT_OF_PLACE_START:
-                    eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l], x_in=xb[:rows], **kw)
+                    eng.layers(s0[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l], x_in=s0[:rows], **kw)
                 else:
-                    xb[(k + 1) * rows:(k + 2) * rows].copy_(xb[:rows])
-                    eng.layers(xb[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l], **kw)
+                    s0[(k + 1) * rows:(k + 2) * rows].copy_(s0[:rows])
+                    eng.layers(s0[(k + 1) * rows:(k + 2) * rows], n, l, l + 1, [l], **kw)
             skip = [l] if l in removed_set else None
             if score is not None:
-                eng.layers(xb[:(k + 1) * rows], (k + 1) * n, l, l + 1, skip, site, chain, bs, g, score_images=n)
+                eng.layers(xb[:x0 + (k + 1) * rows], n_x + (k + 1) * n, l, l + 1, skip, site, chain, bs, g, score_images=n_x + n)
             else:
                 eng.layers(xb[:(k + 1) * rows], (k + 1) * n, l, l + 1, skip, **kw)
             if l in cand_set:
                 started.append(l)
         if score is not None:
-            # the hook of the LAST block, out of place into the spare slot (slot 0 stays what the tails read) and BEFORE the tails: the
+            # the hook of the LAST block, out of place into the spare area (slot 0 stays what the tails read) and BEFORE the tails: the
             # scores are then complete while the latency-bound tails still run — a caller's host mask step overlaps them
-            spare_x = xb[slots * rows:(slots + 1) * rows] if xb.shape[0] >= (slots + 1) * rows else torch.empty(rows, xb.shape[1], dtype=xb.dtype, device=xb.device)
-            eng.layers(spare_x, n, L - 1, L, None, site, chain, bs, g, scores_only=True, x_in=xb[:rows])
+            at = x0 + slots * rows
+            spare_x = xb[at:at + x0 + rows] if xb.shape[0] >= at + x0 + rows else torch.empty(x0 + rows, xb.shape[1], dtype=xb.dtype, device=xb.device)
+            eng.layers(spare_x, n_x + n, L - 1, L, None, site, chain, bs, g, scores_only=True, x_in=xb[:x0 + rows])
+        xb = s0                                               # from here on: the slots only (what the tails read)
 
         def tails():
             # the baseline (slot 0) and every candidate under way meet the same last block and classifier: ONE tail over all the
@@ -621,7 +642,10 @@ def depth_search_counts(engine, dataloader, depth: int, *, batch_limit: Optional
 
 # what the last prune_pass of this process did (bench.py prints it: a run that silently fell back to the candidate-major order,
 # because its engine was sized without the slab padding, is then visible)
-PASS_STATS = {"fused_chunks": 0, "fused_layer_major": 0, "search_only_chunks": 0, "scores_only_launches": 0,
+# hook-only calibration batches (inside the score limit, outside the search's) ride in front of slot 0 of the last scored chunk instead of
+# getting launches of their own (0: the scores-only forward of rounds 1-5a; same scores either way)
+FUSE_EXTRAS = os.environ.get("SSP2_FUSE_EXTRAS", "1") != "0"
+PASS_STATS = {"fused_chunks": 0, "fused_layer_major": 0, "search_only_chunks": 0, "scores_only_launches": 0, "hook_only_batches_fused": 0,
               "score_batches_owned": 0, "search_batches_owned": 0}      # the last two: 0 on a rank that idles in that stage (fewer batches than ranks)
 
 
@@ -673,6 +697,7 @@ def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int,
     seen_score = [0, 0]                      # batches / samples this rank SAW inside the score limit
     state = {"eng": None, "counts": None, "total": 0, "s1": None, "tails": None}
     fused: List[Tuple[int, torch.Tensor, torch.Tensor, bool]] = []      # (global index, pixels, labels, scored?) of the open search chunk
+    extras: List[Tuple[int, torch.Tensor]] = []                          # hook-only batches that ride on it (global index, pixels)
 
     def resolve(n: int):
         base = max(chunk_images, n)
@@ -686,6 +711,11 @@ def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int,
                 lm_imgs = lm_capacity_images(int(tk), slots, n_chunk, n) if tk else int(slots * n_chunk * 1.05) + 64
                 if lm_imgs * per_image() <= workspace_budget_bytes():
                     need = max(need, lm_imgs)
+                    # ... and room for hook-only batches in front of slot 0 (up to one slot's worth), when stage 1 takes more batches than the search
+                    more = (lm_capacity_images(int(tk), slots + 1, n_chunk, n) if tk else lm_imgs + n_chunk + 64)
+                    if FUSE_EXTRAS and (score_limit is None or search_limit is None or int(score_limit) > int(search_limit)) \
+                            and more * per_image() <= workspace_budget_bytes():
+                        need = max(need, more)
             eng = engine(need)
         else:
             eng = engine
@@ -694,12 +724,12 @@ def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int,
         state["s1"] = _Chunker(min(eng.max_images, base), eng.device, max_batches=MAX_SLABS)
         return eng
 
-    def fits_lm(eng, n: int, g: int) -> bool:
-        if not want_lm or eng.max_images < slots * n:
+    def fits_lm(eng, n: int, g: int, n_x: int = 0) -> bool:
+        if not want_lm or eng.max_images < slots * n + n_x:
             return False
         if not getattr(eng, "prefix_scoring", False):
-            return True
-        return eng.max_images * eng.tokens + 16 * 256 >= slots * slab_rows(eng.tokens, n, g)
+            return n_x == 0
+        return eng.max_images * eng.tokens + 16 * 256 >= slots * slab_rows(eng.tokens, n, g) + (slab_rows(eng.tokens, n_x, g) if n_x else 0)
 
     def run_pending():          # the CLS-only tails of the previous scored chunk (held back so that its scores could leave first)
         t, state["tails"] = state["tails"], None
@@ -718,14 +748,25 @@ def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int,
         px = items[0][1] if len(items) == 1 else ([it[1] for it in items] if as_list else torch.cat([it[1] for it in items], 0))
         labels = items[0][2] if len(items) == 1 else torch.cat([it[2] for it in items], 0)
         run_pending()
+        ex = list(extras); extras.clear()
+        n_x = sum(int(e[1].size(0)) for e in ex)
+        if ex and not (scored and getattr(eng, "prefix_scoring", False) and fits_lm(eng, n, g, n_x)):
+            for e in ex:                                      # (cannot ride after all: their own scores-only forward, as before)
+                vec = eng.forward_scores(e[1], site, score_chain, int(e[1].size(0)))
+                PASS_STATS["scores_only_launches"] += 1
+                local.append((e[0], vec[0]))
+            ex, n_x = [], 0
         if getattr(eng, "prefix_scoring", False):
             if scored:
-                lm_now = fits_lm(eng, n, g)
-                PASS_STATS["fused_chunks"] += 1; PASS_STATS["fused_layer_major"] += int(lm_now)
+                lm_now = fits_lm(eng, n, g, n_x)
+                PASS_STATS["fused_chunks"] += 1; PASS_STATS["fused_layer_major"] += int(lm_now); PASS_STATS["hook_only_batches_fused"] += len(ex)
                 bs, state["tails"] = _search_chunk(eng, px, labels, n, L, cands, (), state["counts"], slots=slots, lm=lm_now,
-                                                   group=g, score=(site, score_chain), defer_tail=True)
+                                                   group=g, score=(site, score_chain), defer_tail=True,
+                                                   extra_px=([e[1] for e in ex] if len(ex) > 1 else ex[0][1]) if ex else None)
+                for k, e in enumerate(ex):                    # the extras' score rows come first
+                    local.append((e[0], bs[k]))
                 for k, it in enumerate(items):
-                    local.append((it[0], bs[k]))
+                    local.append((it[0], bs[len(ex) + k]))
             else:
                 PASS_STATS["search_only_chunks"] += 1
                 _search_chunk(eng, px, labels, n, L, cands, (), state["counts"], slots=slots, lm=want_lm and eng.max_images >= slots * n)
@@ -768,6 +809,14 @@ def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int,
                 flush_fused()
             fused.append((gi, _pixels_to_device(batch, eng.device), _to_device(batch["labels"], eng.device, torch.int64), in_score))
         elif in_score:
+            n_open = sum(int(it[1].size(0)) for it in fused)
+            n_x = sum(int(e[1].size(0)) for e in extras)
+            if (FUSE_EXTRAS and fused and fused[0][3] and int(fused[0][1].size(0)) == n and n_x + n <= n_open
+                    and getattr(eng, "prefix_scoring", False) and fits_lm(eng, n_open, n, n_x + n)):
+                # a hook-only batch while a scored chunk is still open (the search's batches come first in the loader): it rides in front of
+                # that chunk's slot 0 — no launches of its own — as long as the extras stay within one slot's worth and the workspace holds them
+                extras.append((gi, _pixels_to_device(batch, eng.device)))
+                continue
             flush_fused()
             if state["s1"].full_for(n):
                 flush_s1()

@@ -627,6 +627,8 @@ def main():
         if not args.two_pass and not (args.two_streams or args.overlap_stage1):
             # one pass: the search's streams are in the slab layout of the stage-1 hook (every 64-image batch padded to 256 rows)
             cap = max(cap, core.lm_capacity_images(tokens, depth, max(1, eval_chunk // args.batch) * args.batch, args.batch))
+            if n_calib > n_eval:       # + the calibration batches the search does not take: they ride in front of slot 0 (hook only)
+                cap += -(-core.slab_rows(tokens, min(n_calib - n_eval, eval_chunk) // args.batch * args.batch, args.batch) // tokens) + args.batch
     eng = VitEngine(weights, device=dev, max_images=cap, precision=args.precision)
     # --two-streams: stage 1 (calibration scores) and stage 2 (depth search on the dense model) are independent, and so
     # are the search candidates: with a second engine workspace (weights uploaded twice, 173 MB) on a second HIP stream
@@ -852,9 +854,10 @@ def main():
                                 "launches": prof.launches, "avg_launch_us": round(prof.total_ms * 1e3 / prof.launches, 2),
                                 "flops_per_launch_avg": prof.flops / prof.launches,
                                 "library_yardstick": library_yardstick("fc1") if args.precision == "bf16" and args.model == "vit_base_patch16_224" else None,
-                                "shapes": (f"[{core.slab_rows(tokens, max(1, eval_chunk // args.batch) * args.batch, args.batch)} hooked | the same x 0..{depth - 2} unhooked | "
-                                           f"{eng.rows(max(n_calib - n_eval, args.batch), args.batch) if n_calib > n_eval else 0} | {eval_chunk}] x {d_int} x {dim} (the search chunk's baseline in {args.batch}-image slabs, "
-                                           f"carrying the stage-1 hook | the candidates under way in the same launch sequence | scores-only launch of the calibration batches the search does not take | CLS tail)"
+                                "shapes": (f"[{core.slab_rows(tokens, max(1, eval_chunk // args.batch) * args.batch + (core.PASS_STATS['hook_only_batches_fused'] * args.batch), args.batch)} hooked | "
+                                           f"{core.slab_rows(tokens, max(1, eval_chunk // args.batch) * args.batch, args.batch)} x 0..{depth - 2} unhooked | {eval_chunk}] x {d_int} x {dim} "
+                                           f"(the search chunk's baseline in {args.batch}-image slabs + the {core.PASS_STATS['hook_only_batches_fused']} calibration batches the search does not take, "
+                                           f"all carrying the stage-1 hook | the candidates under way, second launch of the same block | CLS tail)"
                                            if one_pass else
                                            f"[{eng.rows(min(n_calib, calib_chunk), args.batch)} | {eval_chunk * tokens} | {eval_chunk}] x {d_int} x {dim} (stage-1 launch in {args.batch}-image slabs | search chunk{lm} | CLS tail)")}
         if args.precision == "fp8":
