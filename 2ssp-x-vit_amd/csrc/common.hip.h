@@ -207,9 +207,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // Row layout of the token matrix.  group == 0: images are contiguous (row of image i = i * tokens).
 // group  > 0: the images are laid out in SLABS of `group` images (= one dataloader batch each), every slab padded to
-// `mpad` rows (a multiple of 256, so no GEMM tile straddles two slabs).  A sample then sits at the same offset inside
-// its slab whichever launch it is part of, which makes the per-tile partial sums of the fused stage-1 score — and so
-// the scores — independent of how many batches share a launch.
+// `mpad` rows, a multiple of kSlabAlign = 128: the stage-1 hook folds a sample's sum of squares per 128-row tile (a tile of the 128 x 128
+// kernel = a wave's tile of the 256 x 256 kernel), so no such tile straddles two slabs and a sample sits at the same offset inside its tile
+// grid whichever launch it is part of — which makes the per-tile partial sums, and so the scores, independent of how many batches share a
+// launch.  (Rounds 1-5a aligned slabs to 256 rows; only the 128-row scoring tiles need the alignment — a 256-row workgroup tile may span two
+// slabs — and with the search's streams in this layout since round 5 the pad rows are work: 64 instead of 192 per 64 images of ViT-B/16.)
+static constexpr int kSlabAlign = 128;
 struct RowMap { int tokens, group, mpad; };
 __host__ __device__ __forceinline__ long row_of(const RowMap r, int img) {
   return r.group > 0 ? (long)(img / r.group) * r.mpad + (long)(img % r.group) * r.tokens : (long)img * r.tokens;

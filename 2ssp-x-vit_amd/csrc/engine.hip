@@ -40,10 +40,10 @@ static int fail(int code, const char* fmt, ...) {
 
 static inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 
-// slab layout (common.hip.h RowMap): `group` images per slab, slabs padded to a multiple of 256 rows
+// slab layout (common.hip.h RowMap): `group` images per slab, slabs padded to a multiple of kSlabAlign = 128 rows
 static inline RowMap make_rowmap(int tokens, int n, int group) {
   RowMap r{tokens, 0, 0};
-  if (group > 0 && group < n) { r.group = group; r.mpad = ceil_to(group * tokens, 256); }
+  if (group > 0 && group < n) { r.group = group; r.mpad = ceil_to(group * tokens, kSlabAlign); }
   return r;
 }
 static inline long total_rows(const RowMap& r, int n) {
@@ -930,7 +930,7 @@ int ssp2_layers_from(ssp2_handle e, const float* x_in, float* x, int n, int l_be
 // score_images < n: only the LEADING score_images images of the launch are hooked (whole slabs of the slab layout).  This is the depth
 // search's baseline doubling as the stage-1 pass (reference: ONE loader and ONE batch_limit feed both stages,
 // adaptation-for-Pures-framework/mask_conjunction.py:276-281, :327): slot 0 of the layer-major launch is scored, the candidates' slots
-// behind it are not.  Only the fc1 GEMM is split in two launches at the (256-row aligned) slab boundary; a row's arithmetic does not
+// behind it are not.  Only the fc1 GEMM is split in two launches at the (128-row aligned) slab boundary; a row's arithmetic does not
 // depend on the launch it is part of, so the stream and the scores are the bits of a scored launch of score_images images alone.
 int ssp2_layers_prefix(ssp2_handle e, const float* x_in, float* x, int n, int l_begin, int l_end, const uint8_t* attn_skip, int score_site,
                        int score_chain, int score_group, int score_images, float* batch_scores, int score_ld) {

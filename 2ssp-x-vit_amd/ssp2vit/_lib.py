@@ -13,6 +13,7 @@ CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libssp2vit.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 
+SLAB_ALIGN = 128                                        # csrc/common.hip.h kSlabAlign: slabs of the slab layout are padded to a multiple of this many rows
 ABI_VERSION = 4                                         # SSP2_ABI_VERSION of include/ssp2vit.h
 
 # every symbol include/ssp2vit.h declares

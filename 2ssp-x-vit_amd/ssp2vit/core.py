@@ -11,6 +11,7 @@ from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 import torch
 
 from . import dist as _dist
+from ._lib import SLAB_ALIGN
 from .mask_parity import mask_parity_report
 
 
@@ -209,7 +210,7 @@ def stage1_scores(engine, dataloader, d_ints: Sequence[int], site: str, *, batch
 
     Several dataloader batches share one forward (`chunk_images`, default SSP2_CHUNK_IMAGES).  A sample's sum of
     squares is folded per 128-row GEMM tile, so its fp32 rounding depends on where the sample sits relative to the
-    tile grid; every batch is therefore laid out as its own 256-row-aligned slab (ssp2_rows / RowMap), which pins
+    tile grid; every batch is therefore laid out as its own 128-row-aligned slab (ssp2_rows / RowMap), which pins
     that position: scores are bit-identical for every packing and every world size.
 
     `defer=True` (fp32 chain) returns a zero-argument callable instead of the list: all device work is enqueued, the
@@ -430,7 +431,7 @@ def top1_counts(engine, dataloader, *, max_batches=None, progress=False, process
 def slab_rows(tokens: int, n: int, group: int) -> int:
     """Rows one SLOT of n images takes in the slab layout with `group` images per slab, every slab padded (n a multiple of group):
     slot s of a layer-major launch then begins at slab s * n / group of the launch's row map (csrc/common.hip.h RowMap)."""
-    mpad = (group * tokens + 255) // 256 * 256
+    mpad = -(-group * tokens // SLAB_ALIGN) * SLAB_ALIGN
     return (n // group) * mpad
 
 
@@ -669,7 +670,7 @@ def prune_pass(engine, dataloader, d_ints: Sequence[int], site: str, depth: int,
     `self.dl[:batch_limit]` (adaptation-for-Pures-framework/mask_conjunction.py:276-281), `_compute_att_depth_importance` evaluates the
     dense model (:327) and every candidate (:345) on `self.dl[:batch_limit]` again; `fit()` runs both (:359-362) and the CLI builds
     the object once (auto_2ssp.py:765-775).  The dense forward over those batches is computed twice there (and L more times with one
-    attention bypassed).  Here a batch that both stages want goes through ONE dense forward: it is laid out as its own 256-row-aligned
+    attention bypassed).  Here a batch that both stages want goes through ONE dense forward: it is laid out as its own 128-row-aligned
     slab (what pins a sample's partial sums of squares, see stage1_scores), the fc1 launches of that baseline carry the stage-1 hook,
     and the candidates of the layer-major search start from its per-block stream as before.  Scores are bit-identical to
     stage1_scores (slab position) and counts to depth_search_counts (no result of a row depends on the launch it is part of).

@@ -282,7 +282,7 @@ class VitEngine:
             n = sum(int(p.shape[0]) for p in pixels)
             x = self.new_x(n, group) if x is None else x
             if group > 0 and group < n:
-                mpad = (group * self.tokens + 255) // 256 * 256
+                mpad = -(-group * self.tokens // _lib.SLAB_ALIGN) * _lib.SLAB_ALIGN
                 pad = mpad - group * self.tokens
                 if pad:                                    # pad rows between slabs: finite values (they flow through LN / GEMMs)
                     x[: (len(pixels) - 1) * mpad].view(len(pixels) - 1, mpad, self.dim)[:, group * self.tokens:, :].zero_()
@@ -407,7 +407,7 @@ class VitEngine:
         n = sum(int(p.shape[0]) for p in pixels) if isinstance(pixels, (list, tuple)) else pixels.shape[0]
         if n > self.max_images:
             raise Ssp2Error(f"chunk of {n} images exceeds engine capacity {self.max_images}")
-        x = self.embed(pixels, group=group)             # slab layout: one 256-row-aligned slab per batch
+        x = self.embed(pixels, group=group)             # slab layout: one 128-row-aligned slab per batch
         return self.layers(x, n, 0, self.depth, None, score_site, score_chain, None, group, scores_only=True)
 
     def forward_logits(self, pixels: torch.Tensor, attn_skip: Optional[Sequence[int]] = None) -> torch.Tensor:

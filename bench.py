@@ -625,7 +625,7 @@ def main():
     if args.batch_candidates:
         cap = max(cap, depth * eval_chunk)
         if not args.two_pass and not (args.two_streams or args.overlap_stage1):
-            # one pass: the search's streams are in the slab layout of the stage-1 hook (every 64-image batch padded to 256 rows)
+            # one pass: the search's streams are in the slab layout of the stage-1 hook (every batch padded to a multiple of 128 rows)
             cap = max(cap, core.lm_capacity_images(tokens, depth, max(1, eval_chunk // args.batch) * args.batch, args.batch))
             if n_calib > n_eval:       # + the calibration batches the search does not take: they ride in front of slot 0 (hook only)
                 cap += -(-core.slab_rows(tokens, min(n_calib - n_eval, eval_chunk) // args.batch * args.batch, args.batch) // tokens) + args.batch

@@ -141,7 +141,7 @@ float ssp2_fp8_attn_scale(ssp2_handle h, int layer);                     /* > 0,
 int ssp2_fp8_set_attn_scale(ssp2_handle h, int layer, float scale);
 
 /* Row layout of the token matrix x.  group <= 0 or >= n: images contiguous, ssp2_rows = n*N.  0 < group < n: SLABS of
- * `group` images (one dataloader batch each), every slab padded to a multiple of 256 rows — a sample then sits at the
+ * `group` images (one dataloader batch each), every slab padded to a multiple of 128 rows (the hook's tile) — a sample then sits at the
  * same offset inside its slab whichever call it is part of, so per-tile partial sums (hence stage-1 scores) do not
  * depend on how many batches share a call.  ssp2_embed / ssp2_layers / ssp2_head of one forward take the same group. */
 long ssp2_rows(ssp2_handle h, int n, int group);

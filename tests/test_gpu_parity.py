@@ -280,7 +280,7 @@ def test_copy_mode_selection_and_width_prune_end_to_end(gpu):
 
 def test_eval_chunking_is_exact_and_stage1_packing_is_bit_identical(gpu):
     """Stage-2 / top-1 counts are integers: packing several dataloader batches into one forward must not change
-    them.  Stage-1 packing lays every batch out as its own 256-row-aligned slab (ssp2_rows), so a sample meets the
+    them.  Stage-1 packing lays every batch out as its own 128-row-aligned slab (ssp2_rows), so a sample meets the
     same GEMM tiles whichever launch it is part of: scores are BIT-IDENTICAL to one batch per forward."""
     from oracle.vit_modules import build_from_flat
     from ssp2vit import core, vit_pruning as vp
@@ -943,7 +943,7 @@ def test_full_depth_large_geometries_vs_reference_golden(gpu, name, tag, layout)
     """BASELINE configs[3] / configs[4] geometries at FULL depth against outputs of the REAL reference (tests/golden/<tag>.npz,
     make_golden.py --l16 / --h14): ViT-L/16 (24 blocks, old-HF anatomy: post-GELU hook, tuple-returning attention, eps 1e-12) on
     2 x 12 images and ViT-H/14 (32 blocks, 257 tokens, d_h = 80, timm anatomy: pre-GELU hook) on 2 x 8 images, 1000 classes, the
-    bench's weights.  Both batches of the stage-1 pass share ONE launch of two 256-row-aligned slabs = 5120 / 4608 rows >= 4096,
+    bench's weights.  Both batches of the stage-1 pass share ONE launch of two 128-row-aligned slabs = 4796 / 4232 rows >= 4096 (round 5; 256-row slabs before),
     so every projection of it runs on the PERSISTENT 256 x 256 kernel at K = 1024 / 1280 / 4096 / 5120 (asserted on the row
     count); the layer-major search reaches (l + 1) x n images per launch.  The dense logits are taken twice — default routing
     (128 x 128 kernel at 12 / 8 images) and with SSP2_OPT_BIG_TILE_MIN_ROWS lowered so the same images meet the large kernel.
@@ -1836,7 +1836,8 @@ def test_patch_embed_with_lds_staged_patch_tiles_gives_the_im2col_paths_bits(gpu
                 b = eng.embed(px, group=group).clone()
                 torch.cuda.synchronize()
                 if group:
-                    mpad, ntok = eng.rows(group, group), eng.tokens
+                    ntok = eng.tokens
+                    mpad = eng.rows(2 * group, group) - eng.rows(group, group)          # the slab stride (a lone slab is not padded)
                     valid = torch.cat([torch.arange(s0 * mpad, s0 * mpad + min(group, n - s0 * group) * ntok)
                                        for s0 in range((n + group - 1) // group)]).to(gpu)
                     a, b = a[valid], b[valid]
@@ -1881,8 +1882,8 @@ def test_out_of_place_block_input_equals_copy_then_in_place(gpu):
     cat = torch.cat(parts, 0)
     assert torch.equal(eng.embed(parts), eng.embed(cat))
     a, b = eng.embed(parts, group=8), eng.embed(cat, group=8)
-    mpad, ntok = eng.rows(8, 8), eng.tokens
-    mpad = (8 * ntok + 255) // 256 * 256
+    ntok = eng.tokens
+    mpad = eng.rows(16, 8) - eng.rows(8, 8)                        # the slab stride (a lone slab is not padded)
     valid = torch.cat([torch.arange(s0 * mpad, s0 * mpad + min(8, 29 - s0 * 8) * ntok) for s0 in range(4)]).to(gpu)
     assert torch.equal(a[valid], b[valid])
     pads = torch.cat([torch.arange(s0 * mpad + 8 * ntok, (s0 + 1) * mpad) for s0 in range(3)]).to(gpu)
