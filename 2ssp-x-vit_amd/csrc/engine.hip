@@ -777,39 +777,85 @@ static int upload_f32(ssp2_engine* e, float* dst, const float* src, size_t numel
   return 0;
 }
 
-static int load_tensor_impl(ssp2_handle e, int kind, int layer, const float* src, size_t numel, bool dev);
-int ssp2_load_tensor(ssp2_handle e, int kind, int layer, const float* host, size_t numel) { return load_tensor_impl(e, kind, layer, host, numel, false); }
-int ssp2_load_tensor_dev(ssp2_handle e, int kind, int layer, const float* dev_ptr, size_t numel) { return load_tensor_impl(e, kind, layer, dev_ptr, numel, true); }
-
-static int load_tensor_impl(ssp2_handle e, int kind, int layer, const float* host, size_t numel, bool dev) {
-  if (!e || !host) return fail(SSP2_EINVAL, "null argument");
+// where a tensor kind goes: a weight matrix's bf16 image, its bias, or an fp32 vector kept as it is
+struct IngestTarget { int type = 2; Mat* m = nullptr; float* dst = nullptr; size_t expect = 0; bool* flag = nullptr; };
+static int resolve_tensor(ssp2_engine* e, int kind, int layer, IngestTarget* t) {
   const int D = e->d.dim;
   const bool per_layer = kind >= SSP2_T_LN1_G && kind <= SSP2_T_FC2_B;
   if (per_layer && (layer < 0 || layer >= e->d.depth)) return fail(SSP2_EINVAL, "layer %d out of range", layer);
   Layer* L = per_layer ? &e->layers[layer] : nullptr;
+  auto mat = [&](Mat& m) { t->type = 0; t->m = &m; t->expect = (size_t)m.rows * m.cols; return 0; };
+  auto bias = [&](Mat& m) { t->type = 1; t->m = &m; t->expect = (size_t)m.rows; return 0; };
+  auto vec = [&](float* dst, size_t expect, bool* flag) { t->type = 2; t->dst = dst; t->expect = expect; t->flag = flag; return 0; };
   switch (kind) {
-    case SSP2_T_PATCH_W: return upload_matrix(e, e->patch, host, numel, dev);
-    case SSP2_T_PATCH_B: return upload_bias(e, e->patch, host, numel, dev);
-    case SSP2_T_CLS: return upload_f32(e, e->cls, host, numel, D, &e->misc_set[0], dev);
-    case SSP2_T_POS: return upload_f32(e, e->pos, host, numel, (size_t)e->tokens * D, &e->misc_set[1], dev);
-    case SSP2_T_LN1_G: return upload_f32(e, L->ln1_g, host, numel, D, &L->ln_set[0], dev);
-    case SSP2_T_LN1_B: return upload_f32(e, L->ln1_b, host, numel, D, &L->ln_set[1], dev);
-    case SSP2_T_LN2_G: return upload_f32(e, L->ln2_g, host, numel, D, &L->ln_set[2], dev);
-    case SSP2_T_LN2_B: return upload_f32(e, L->ln2_b, host, numel, D, &L->ln_set[3], dev);
-    case SSP2_T_QKV_W: return upload_matrix(e, L->qkv, host, numel, dev);
-    case SSP2_T_QKV_B: return upload_bias(e, L->qkv, host, numel, dev);
-    case SSP2_T_PROJ_W: return upload_matrix(e, L->proj, host, numel, dev);
-    case SSP2_T_PROJ_B: return upload_bias(e, L->proj, host, numel, dev);
-    case SSP2_T_FC1_W: return upload_matrix(e, L->fc1, host, numel, dev);
-    case SSP2_T_FC1_B: return upload_bias(e, L->fc1, host, numel, dev);
-    case SSP2_T_FC2_W: return upload_matrix(e, L->fc2, host, numel, dev);
-    case SSP2_T_FC2_B: return upload_bias(e, L->fc2, host, numel, dev);
-    case SSP2_T_LNF_G: return upload_f32(e, e->lnf_g, host, numel, D, &e->misc_set[2], dev);
-    case SSP2_T_LNF_B: return upload_f32(e, e->lnf_b, host, numel, D, &e->misc_set[3], dev);
-    case SSP2_T_HEAD_W: return upload_matrix(e, e->head, host, numel, dev);
-    case SSP2_T_HEAD_B: return upload_bias(e, e->head, host, numel, dev);
+    case SSP2_T_PATCH_W: return mat(e->patch);
+    case SSP2_T_PATCH_B: return bias(e->patch);
+    case SSP2_T_CLS: return vec(e->cls, D, &e->misc_set[0]);
+    case SSP2_T_POS: return vec(e->pos, (size_t)e->tokens * D, &e->misc_set[1]);
+    case SSP2_T_LN1_G: return vec(L->ln1_g, D, &L->ln_set[0]);
+    case SSP2_T_LN1_B: return vec(L->ln1_b, D, &L->ln_set[1]);
+    case SSP2_T_LN2_G: return vec(L->ln2_g, D, &L->ln_set[2]);
+    case SSP2_T_LN2_B: return vec(L->ln2_b, D, &L->ln_set[3]);
+    case SSP2_T_QKV_W: return mat(L->qkv);
+    case SSP2_T_QKV_B: return bias(L->qkv);
+    case SSP2_T_PROJ_W: return mat(L->proj);
+    case SSP2_T_PROJ_B: return bias(L->proj);
+    case SSP2_T_FC1_W: return mat(L->fc1);
+    case SSP2_T_FC1_B: return bias(L->fc1);
+    case SSP2_T_FC2_W: return mat(L->fc2);
+    case SSP2_T_FC2_B: return bias(L->fc2);
+    case SSP2_T_LNF_G: return vec(e->lnf_g, D, &e->misc_set[2]);
+    case SSP2_T_LNF_B: return vec(e->lnf_b, D, &e->misc_set[3]);
+    case SSP2_T_HEAD_W: return mat(e->head);
+    case SSP2_T_HEAD_B: return bias(e->head);
     default: return fail(SSP2_EINVAL, "unknown tensor kind %d", kind);
   }
+}
+
+static int load_tensor_impl(ssp2_handle e, int kind, int layer, const float* src, size_t numel, bool dev) {
+  if (!e || !src) return fail(SSP2_EINVAL, "null argument");
+  IngestTarget t;
+  if (int rc = resolve_tensor(e, kind, layer, &t)) return rc;
+  if (t.type == 0) return upload_matrix(e, *t.m, src, numel, dev);
+  if (t.type == 1) return upload_bias(e, *t.m, src, numel, dev);
+  return upload_f32(e, t.dst, src, numel, t.expect, t.flag, dev);
+}
+int ssp2_load_tensor(ssp2_handle e, int kind, int layer, const float* host, size_t numel) { return load_tensor_impl(e, kind, layer, host, numel, false); }
+int ssp2_load_tensor_dev(ssp2_handle e, int kind, int layer, const float* dev_ptr, size_t numel) { return load_tensor_impl(e, kind, layer, dev_ptr, numel, true); }
+
+// Many device-resident tensors at once (a live module's ~150 parameters): every entry is validated first — nothing is enqueued when one
+// is wrong —, then the batch goes out in launches of up to kIngestBatch tensors (ingest_batch_kernel; the descriptors are the kernel
+// argument).  Same bits as ssp2_load_tensor_dev entry by entry.
+int ssp2_load_tensors_dev(ssp2_handle e, int count, const int* kinds, const int* layers, const float* const* dev_ptrs, const size_t* numels) {
+  if (!e || count < 0 || (count && (!kinds || !layers || !dev_ptrs || !numels))) return fail(SSP2_EINVAL, "null argument");
+  std::vector<IngestTarget> ts((size_t)count);
+  for (int i = 0; i < count; ++i) {
+    if (!dev_ptrs[i]) return fail(SSP2_EINVAL, "entry %d: null tensor", i);
+    if (int rc = resolve_tensor(e, kinds[i], layers[i], &ts[i])) return rc;
+    if (numels[i] != ts[i].expect) return fail(SSP2_EINVAL, "entry %d (kind %d, layer %d) expects %zu values, got %zu", i, kinds[i], layers[i], ts[i].expect, numels[i]);
+  }
+  for (int at = 0; at < count; at += kIngestBatch) {
+    IngestBatch b;
+    b.count = std::min(kIngestBatch, count - at);
+    unsigned long work = 0;
+    for (int k = 0; k < b.count; ++k) {
+      const IngestTarget& t = ts[at + k];
+      IngestDesc& d = b.d[k];
+      d.src = dev_ptrs[at + k]; d.type = t.type;
+      if (t.type == 0) { d.dst = t.m->w; d.rows = t.m->rows; d.cols = t.m->cols; d.rows_pad = t.m->rows_pad; d.ld = t.m->ld; work += (unsigned long)t.m->rows_pad * (t.m->ld / 8); }
+      else if (t.type == 1) { d.dst = t.m->b; d.rows = t.m->rows; d.cols = 1; d.rows_pad = t.m->rows_pad; d.ld = 0; work += (unsigned long)(t.m->rows_pad + 7) / 8; }
+      else { d.dst = t.dst; d.rows = (int)t.expect; d.cols = 1; d.rows_pad = (int)t.expect; d.ld = 0; work += (unsigned long)(t.expect + 7) / 8; }
+      if (work > 0xffffffffUL) return fail(SSP2_EINVAL, "ingest batch too large");
+      d.work_end = (unsigned)work;
+    }
+    if (!work) continue;
+    hipLaunchKernelGGL(ingest_batch_kernel, dim3((unsigned)std::min<unsigned long>((work + 255) / 256, 8192)), dim3(256), 0, e->stream, b);
+    HIPCHK(hipGetLastError());
+  }
+  for (int i = 0; i < count; ++i) {
+    if (ts[i].type == 0) ts[i].m->w_set = true; else if (ts[i].type == 1) ts[i].m->b_set = true; else *ts[i].flag = true;
+  }
+  return 0;
 }
 
 static int check_n(ssp2_engine* e, int n, int group = 0) {

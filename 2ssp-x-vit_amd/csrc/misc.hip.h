@@ -376,6 +376,46 @@ __global__ void round_bias_kernel(const float* __restrict__ src, float* __restri
   if (i < n_pad) dst[i] = i < n ? bf16_round(src[i]) : 0.f;
 }
 
+// Weight ingest of MANY device-resident tensors in one launch (ssp2_load_tensors_dev).  A live module hands over ~150 tensors (ViT-B/16);
+// one convert / round / copy launch each was 1.5 ms of launches for 0.1 ms of memory traffic inside the caller's prune bracket.  The
+// descriptors travel as the kernel argument (no table in HBM, nothing to keep alive on the host); a work unit is one 8-element chunk of
+// a destination — the very chunk of convert_pad_bf16_kernel / 8 elements of round_bias_kernel / 8 floats of a plain copy —, units are
+// numbered through all tensors of the batch (work_end = running total) and a thread finds its tensor by bisection in LDS.
+struct IngestDesc {
+  const float* src; void* dst;
+  int rows, cols, rows_pad, ld;       // matrix: source [rows, cols], image [rows_pad, ld]; bias: rows = n, rows_pad = n_pad; copy: rows = n
+  int type;                           // 0 matrix -> bf16 image, 1 bias -> bf16-rounded fp32, 2 fp32 copy
+  unsigned work_end;                  // units of tensors 0 .. this one
+};
+constexpr int kIngestBatch = 64;      // 64 x 40 B + 8 = 2568 B of kernel argument (limit 4 KiB)
+struct IngestBatch { IngestDesc d[kIngestBatch]; int count; };
+__global__ __launch_bounds__(256) void ingest_batch_kernel(const IngestBatch b) {
+  __shared__ IngestDesc ds[kIngestBatch];
+  for (int i = threadIdx.x; i < b.count; i += blockDim.x) ds[i] = b.d[i];
+  __syncthreads();
+  const unsigned total = ds[b.count - 1].work_end;
+  for (unsigned u = blockIdx.x * blockDim.x + threadIdx.x; u < total; u += gridDim.x * blockDim.x) {
+    int lo = 0, hi = b.count - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ds[mid].work_end > u) hi = mid; else lo = mid + 1; }
+    const IngestDesc d = ds[lo];
+    const unsigned i = u - (lo ? ds[lo - 1].work_end : 0u);
+    if (d.type == 0) {
+      const int chunks = d.ld / 8;
+      const int r = (int)(i / chunks), c0 = (int)(i - (unsigned)r * chunks) * 8;
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (bf16)((r < d.rows && c0 + j < d.cols) ? d.src[(size_t)r * d.cols + c0 + j] : 0.f);
+      *(bf16x8*)((bf16*)d.dst + (size_t)r * d.ld + c0) = v;
+    } else if (d.type == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int k = (int)i * 8 + j; if (k < d.rows_pad) ((float*)d.dst)[k] = k < d.rows ? bf16_round(d.src[k]) : 0.f; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int k = (int)i * 8 + j; if (k < d.rows) ((float*)d.dst)[k] = d.src[k]; }
+    }
+  }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // fp8 weight image: bf16 [rows_pad, ld] -> e4m3 bytes [rows_pad, ld8] with one dequantisation scale per row

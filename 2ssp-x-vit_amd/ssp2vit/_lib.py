@@ -14,12 +14,12 @@ LIB_PATH = os.path.join(PKG_ROOT, "lib", "libssp2vit.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 
 SLAB_ALIGN = 128                                        # csrc/common.hip.h kSlabAlign: slabs of the slab layout are padded to a multiple of this many rows
-ABI_VERSION = 4                                         # SSP2_ABI_VERSION of include/ssp2vit.h
+ABI_VERSION = 5                                         # SSP2_ABI_VERSION of include/ssp2vit.h
 
 # every symbol include/ssp2vit.h declares
 SYMBOLS = [
     "ssp2_abi_version", "ssp2_last_error", "ssp2_create", "ssp2_destroy", "ssp2_set_stream", "ssp2_load_tensor",
-    "ssp2_load_tensor_dev", "ssp2_linear_bf16", "ssp2_query", "ssp2_restore_attention", "ssp2_clone_weights",
+    "ssp2_load_tensor_dev", "ssp2_load_tensors_dev", "ssp2_linear_bf16", "ssp2_query", "ssp2_restore_attention", "ssp2_clone_weights",
     "ssp2_prune_ffn_into", "ssp2_set_precision", "ssp2_set_cu_limit", "ssp2_set_option", "ssp2_get_option", "ssp2_profile_query",
     "ssp2_embed", "ssp2_layers", "ssp2_layers_from", "ssp2_layers_prefix", "ssp2_head", "ssp2_tail", "ssp2_tail_slots", "ssp2_tail_group", "ssp2_prune_ffn", "ssp2_drop_attention", "ssp2_d_int", "ssp2_act_l2_accum", "ssp2_profile_begin", "ssp2_profile_end",
     "ssp2_tokens", "ssp2_rows", "ssp2_workspace_bytes", "ssp2_preproc_create", "ssp2_preproc_run", "ssp2_preproc_destroy",
@@ -216,6 +216,7 @@ def load(build_if_missing: bool = True, variant: Optional[str] = None) -> C.CDLL
     lib.ssp2_set_stream.argtypes = [vp, vp]
     lib.ssp2_load_tensor.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.c_size_t]
     lib.ssp2_load_tensor_dev.argtypes = [vp, i32, i32, vp, C.c_size_t]
+    lib.ssp2_load_tensors_dev.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.ssp2_linear_bf16.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, i32, i32]
     lib.ssp2_embed.argtypes = [vp, vp, i32, vp, i32]
     lib.ssp2_rows.argtypes = [vp, i32, i32]

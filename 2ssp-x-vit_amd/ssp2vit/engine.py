@@ -75,14 +75,14 @@ class VitEngine:
         in a kernel; a tensor that already lives on this GPU (a module moved to the device, as the reference keeps it)
         is read in place, a host tensor costs one copy of its fp32 bytes."""
         self._bind_stream()
-        keep = []
+        keep, batch = [], []                                     # device tensors: alive until the stream has consumed them; (kind, layer, tensor)
 
         def put(kind: str, layer: int, t: torch.Tensor):
             t = t.detach()
             if t.device == self.device:
                 t = t.to(torch.float32).contiguous()
-                keep.append(t)                                   # alive until the stream has consumed it
-                self._check(self.lib.ssp2_load_tensor_dev(self.h, T_KINDS.index(kind), layer, C.c_void_p(t.data_ptr()), t.numel()))
+                keep.append(t)
+                batch.append((T_KINDS.index(kind), layer, t))
             else:
                 t = t.to("cpu", torch.float32).contiguous()
                 self._check(self.lib.ssp2_load_tensor(self.h, T_KINDS.index(kind), layer,
@@ -93,7 +93,15 @@ class VitEngine:
             for k in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_g", "ln2_b",
                       "fc1_w", "fc1_b", "fc2_w", "fc2_b"):
                 put(k, i, w[f"{k}.{i}"])
-        if keep:
+        if batch:
+            # a live module's ~150 tensors in ceil(count / 64) launches (ssp2_load_tensors_dev, ABI 5) instead of one launch each: 1.5 ms of
+            # launches for 0.1 ms of traffic inside the caller's prune bracket (scripts/api_profile.py)
+            m = len(batch)
+            kinds = (C.c_int * m)(*[b[0] for b in batch])
+            layers = (C.c_int * m)(*[b[1] for b in batch])
+            ptrs = (C.c_void_p * m)(*[b[2].data_ptr() for b in batch])
+            numels = (C.c_size_t * m)(*[b[2].numel() for b in batch])
+            self._check(self.lib.ssp2_load_tensors_dev(self.h, m, kinds, layers, ptrs, numels))
             torch.cuda.current_stream(self.device).synchronize()
 
     def geometry_key(self):

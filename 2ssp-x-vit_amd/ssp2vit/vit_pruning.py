@@ -260,6 +260,19 @@ def _compute_ffn_activation_importance(vit_model, dataloader, device: str = "cud
 
 
 # ----------------------------------------------------------------------------- a7/a8 width prune (host consumer)
+_LAPS: Optional[dict] = None                 # scripts/api_profile.py sets a dict: host seconds of the a7 / a8 sub-steps are added into it
+
+
+def _lap(name: str, t0: float) -> float:
+    if _LAPS is None:
+        return 0.0
+    import time
+    t1 = time.perf_counter()
+    if name:
+        _LAPS[name] = _LAPS.get(name, 0.0) + (t1 - t0)
+    return t1
+
+
 @torch.no_grad()
 def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: str = "l1", min_remaining: int = 256,
                         n_to_prune_per_block: Optional[List[int]] = None, dataloader=None, device: str = "cuda",
@@ -288,6 +301,7 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
                                                     progress=progress, score_chain=score_chain,
                                                     process_group=process_group)
 
+    t_lap = _lap("", 0.0)
     all_idx: List[List[int]] = []
     all_masks: List[List[int]] = []
     used_scores: List[torch.Tensor] = []
@@ -330,10 +344,12 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
         return b, keep, mask.cpu().tolist(), torch.nonzero(mask == 1).view(-1).tolist()
     # host importances: the blocks are independent and torch releases the interpreter lock inside each call, so a few threads
     # cut them side by side (12 x ~0.26 ms in a row were 3 ms of the prune bracket of the reference-named API); order and results unchanged
+    t_lap = _lap("width: checks", t_lap)
     if len(work) >= 4 and all(w_[1].device.type == "cpu" for w_ in work):
         done = list(_core.mask_pool().map(cut, work))
     else:
         done = [cut(w_) for w_ in work]
+    t_lap = _lap("width: a7 mask step (pool)", t_lap)
     for b, keep, mask_list, idx_list in done:
         if collect_masks:
             all_masks.append(mask_list); all_idx.append(idx_list)
@@ -349,6 +365,7 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
                 moved.append(flat[off:off + k.numel()]); off += k.numel()
             it = iter(moved)
             todo = [(b, next(it) if k.device.type == "cpu" else k) for b, k in todo]
+    t_lap = _lap("width: keep lists to the device", t_lap)
     for b, keep in todo:
         fc1, fc2 = pairs[b]
         w1, b1, w2 = fc1.weight, fc1.bias, fc2.weight
@@ -360,6 +377,7 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
         fc1.in_features = w1.size(1)
         fc2.weight = nn.Parameter(torch.index_select(w2, 1, keep))       # == w2[:, keep].clone()
         fc2.in_features = int(keep.numel())
+    t_lap = _lap("width: a8 gathers + parameters", t_lap)
     if collect_masks:
         site_now = _score_site_of(vit_model)
         # the reference's three keys (:313-318) + this build's cut-margin table for the very scores the masks were cut from

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SSP2_ABI_VERSION 4
+#define SSP2_ABI_VERSION 5
 
 enum {
   SSP2_OK = 0,
@@ -116,6 +116,14 @@ int ssp2_load_tensor(ssp2_handle h, int kind, int layer, const float* host, size
  * padding run in a kernel on the handle's stream.  Asynchronous: dev_ptr must stay valid until the stream has passed
  * this point. */
 int ssp2_load_tensor_dev(ssp2_handle h, int kind, int layer, const float* dev_ptr, size_t numel);
+/* ABI 5: MANY device-resident tensors in one call — entry i is (kinds[i], layers[i], dev_ptrs[i], numels[i]) with the meaning of
+ * ssp2_load_tensor_dev, and the bits it leaves are that call's.  This is how a live module is taken over (the reference hands the
+ * plug-in an nn.Module whose ~150 parameters sit in HBM: `model.to(device)`, adaptation-for-Pures-framework/auto_2ssp.py:693; the
+ * interface reads them, mask_conjunction.py:237-248): the engine issues ceil(count / 64) launches instead of `count`.  Every entry is
+ * validated before anything is enqueued (SSP2_EINVAL names the first wrong one; the engine is then untouched).  Asynchronous on the
+ * handle's stream: every dev_ptrs[i] must stay valid until the stream has passed this point; the four arrays are host memory and are
+ * free to go when the call returns. */
+int ssp2_load_tensors_dev(ssp2_handle h, int count, const int* kinds, const int* layers, const float* const* dev_ptrs, const size_t* numels);
 
 /* Arithmetic of the three large projections (QKV, fc1, fc2) of launches with >= 4096 token rows.
  *   SSP2_PREC_BF16  (default) bf16 operands — the reference's CPU-autocast arithmetic, the parity mode.

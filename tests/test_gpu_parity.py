@@ -1463,6 +1463,50 @@ def test_api_on_a_device_resident_module_matches_the_host_resident_one(gpu):
     assert outs[0][0].shape == (12,) and len(outs[0][1]) == 12
 
 
+def test_batched_ingest_leaves_the_bits_of_one_call_per_tensor_and_validates_before_it_enqueues(gpu):
+    """ssp2_load_tensors_dev (ABI 5): a live module's ~150 device tensors in ceil(count / 64) launches.  Must leave exactly what
+    ssp2_load_tensor_dev leaves tensor by tensor (ViT-Ti/16: 152 tensors = three launches, ragged widths so that padding is exercised),
+    and a wrong entry anywhere in the batch must fail BEFORE anything is enqueued (the engine keeps its previous weights)."""
+    import ctypes as C
+    from ssp2vit import _lib
+    from ssp2vit.engine import VitEngine, Ssp2Error
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=21, std=0.05, eps=1e-6, bias_std=0.02)
+    for i in (1, 7):                                                        # ragged FFN widths: 700 and 333 neurons (not multiples of 8 / 64)
+        keep = 700 if i == 1 else 333
+        w[f"fc1_w.{i}"], w[f"fc1_b.{i}"], w[f"fc2_w.{i}"] = w[f"fc1_w.{i}"][:keep].clone(), w[f"fc1_b.{i}"][:keep].clone(), w[f"fc2_w.{i}"][:, :keep].clone()
+    wd = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in w.items()}
+    px = torch.randn(12, 3, 224, 224, generator=torch.Generator().manual_seed(22)).to(gpu)
+    batched = VitEngine(wd, device=gpu, max_images=16)                   # _load -> ssp2_load_tensors_dev
+    single = VitEngine({k: (torch.zeros_like(v) if torch.is_tensor(v) else v) for k, v in w.items()}, device=gpu, max_images=16)    # zeros through the host path first ...
+    single._bind_stream()
+    keepalive = []
+    for k, v in wd.items():                                                 # ... then every tensor again through the one-tensor device call
+        if not torch.is_tensor(v) or k.startswith("attn_absent"):
+            continue
+        name, _, layer = k.partition(".")
+        t = v.to(torch.float32).contiguous(); keepalive.append(t)
+        single._check(single.lib.ssp2_load_tensor_dev(single.h, _lib.T_KINDS.index(name), int(layer or 0), C.c_void_p(t.data_ptr()), t.numel()))
+    torch.cuda.synchronize()
+    a, b = batched.forward_logits(px), single.forward_logits(px)
+    sa, sb = batched.forward_scores(px, "pre_gelu", "fp32")[0], single.forward_scores(px, "pre_gelu", "fp32")[0]
+    assert torch.equal(a, b) and torch.equal(sa, sb)
+    # a wrong entry (entry 70 of 152: in the SECOND launch's range) — nothing may have been enqueued, not even the first 64 tensors
+    other = synthetic_weights("vit_tiny_patch16_224", classes=10, seed=99, std=0.05, eps=1e-6, bias_std=0.02)
+    ts = [(k, v.to(gpu).float().contiguous()) for k, v in other.items() if torch.is_tensor(v) and not k.startswith("attn_absent") and "fc" not in k]
+    m = len(ts)
+    assert m > 70
+    kinds = (C.c_int * m)(*[_lib.T_KINDS.index(k.partition(".")[0]) for k, _ in ts])
+    layers = (C.c_int * m)(*[int(k.partition(".")[2] or 0) for k, _ in ts])
+    ptrs = (C.c_void_p * m)(*[t.data_ptr() for _, t in ts])
+    numels = (C.c_size_t * m)(*[t.numel() - (1 if i == 70 else 0) for i, (_, t) in enumerate(ts)])
+    with pytest.raises(Ssp2Error, match="entry 70"):
+        batched._check(batched.lib.ssp2_load_tensors_dev(batched.h, m, kinds, layers, ptrs, numels))
+    torch.cuda.synchronize()
+    assert torch.equal(batched.forward_logits(px), a)
+    batched.close(); single.close()
+
+
 # ------------------------------------------------------------------------------------------ fp8 path (opt-in, configs[4])
 @pytest.mark.parametrize("cfg", ["vit_small_patch16_224_d2", "vit_huge_patch14_224_d2"])
 def test_fp8_engine_tracks_the_bf16_engine_within_the_e4m3_tolerance(gpu, cfg):
