@@ -138,13 +138,25 @@ class Auto2SSPInterface(PruningInterface):
                 raise
         if both is not None:
             att, mlp = both
+            # The scores reach the host before the search's CLS-only tails have finished (core.prune_pass sends them first), so the host
+            # takes them FIRST and sorts them while the card is still busy: the descending argsort the a7 mask step of a following
+            # prune_vit_mlp_width(precomputed_importance=...) starts with (vit_pruning.precompute_orders).  Results and the order of the
+            # returned pair are the reference's (:359-362: attention, then MLP); a failure of the MLP half still surfaces after the
+            # attention half's, as it would there.
+            mlp_err = None
+            try:
+                self.mlp_importance = mlp()
+                _vp.precompute_orders(self.mlp_importance)
+            except Exception as e:                            # noqa: BLE001 - re-raised below, in the reference's order
+                mlp_err = e
             try:
                 self.att_importance = att()
             except Exception:
                 if getattr(self, "error_policy", "raise") == "raise":
                     raise
                 self.att_importance = self._heuristic()
-            self.mlp_importance = mlp()
+            if mlp_err is not None:
+                raise mlp_err
             return self.att_importance, self.mlp_importance
         att = self._att_importance_deferred()
         mlp = self._mlp_importance_deferred()

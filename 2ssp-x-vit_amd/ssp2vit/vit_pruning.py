@@ -260,6 +260,32 @@ def _compute_ffn_activation_importance(vit_model, dataloader, device: str = "cud
 
 
 # ----------------------------------------------------------------------------- a7/a8 width prune (host consumer)
+# Descending argsort of importance vectors, computed AHEAD of the mask step while the device is still busy: Auto2SSPInterface.fit() has the
+# stage-1 scores on the host before the search's CLS-only tails have finished, and the a7 mask step that follows in prune_vit_mlp_width
+# starts with exactly this argsort (reference :286) — 55 % of its host time, paid with the card idle when it runs inside the later call.
+# An entry serves the very tensor it was computed from (same object, same in-place version counter) and nothing else; it is the result
+# of the same torch call on the same data, so masks do not depend on whether the cache was hit (tests/test_host_cpu.py).
+_ORDER_CACHE: Dict[int, tuple] = {}
+
+
+def precompute_orders(imps: Sequence[torch.Tensor]) -> None:
+    import weakref
+    _ORDER_CACHE.clear()                                   # one prune's worth: the previous fit()'s tensors are not coming back
+    work = [t for t in imps if isinstance(t, torch.Tensor) and t.device.type == "cpu" and t.dim() == 1]
+    if len(work) < 4:
+        return
+    orders = list(_core.mask_pool().map(lambda t: torch.argsort(t, descending=True), work))
+    for t, o in zip(work, orders):
+        _ORDER_CACHE[id(t)] = (weakref.ref(t), t._version, o)
+
+
+def _order_of(imp: torch.Tensor) -> torch.Tensor:
+    ent = _ORDER_CACHE.get(id(imp))
+    if ent is not None and ent[0]() is imp and ent[1] == imp._version:
+        return ent[2]
+    return torch.argsort(imp, descending=True)
+
+
 _LAPS: Optional[dict] = None                 # scripts/api_profile.py sets a dict: host seconds of the a7 / a8 sub-steps are added into it
 
 
@@ -336,7 +362,7 @@ def prune_vit_mlp_width(vit_model, sparsity: Optional[float] = None, strategy: s
     def cut(item):
         """The reference's mask step for one block (:286-295): the same torch calls on the same 1-D tensor — ties fall as they fall there."""
         b, imp, width, drop = item
-        keep, _ = torch.sort(torch.argsort(imp, descending=True)[: width - drop])
+        keep, _ = torch.sort(_order_of(imp)[: width - drop])
         if not collect_masks:
             return b, keep, None, None
         mask = torch.ones(width, dtype=torch.int16, device=keep.device)

@@ -76,6 +76,36 @@ def test_width_prune_mask_step_matches_reference_golden(layout):
     assert np.array_equal(np.asarray(res["ffn_prune_masks"], dtype=np.int16), z["mask.t100_clamped"])
 
 
+def test_orders_sorted_ahead_of_the_mask_step_change_no_mask_and_serve_only_their_own_tensor():
+    """vit_pruning.precompute_orders (what Auto2SSPInterface.fit() does while the search's tails still run): the a7 mask step of a later
+    prune_vit_mlp_width takes the cached descending argsort only for the very tensor object it was made from, at the same in-place
+    version — masks with a hit, without one, and after the tensor was modified are what the uncached call gives (importances with TIES at
+    the cut, so that the order among equal scores matters)."""
+    from oracle.vit_modules import build_from_flat
+    from ssp2vit import vit_pruning as vp
+    w, _, _ = load_tiny_golden("timm")
+    g = torch.Generator().manual_seed(5)
+    imps = [torch.randint(0, 6, (128,), generator=g).to(torch.float32) for _ in range(4)]           # six levels: ties everywhere
+
+    def masks(importance):
+        res = vp.prune_vit_mlp_width(build_from_flat(w, "timm"), n_to_prune_per_block=[40] * 4, min_remaining=16, collect_masks=True,
+                                     precomputed_importance=importance)
+        return res["ffn_prune_masks"], res["ffn_pruned_indices"]
+    vp._ORDER_CACHE.clear()
+    want = masks(imps)
+    vp.precompute_orders(imps)
+    assert len(vp._ORDER_CACHE) == 4 and all(vp._order_of(t) is vp._ORDER_CACHE[id(t)][2] for t in imps)       # hits
+    assert masks(imps) == want
+    clones = [t.clone() for t in imps]
+    assert all(vp._order_of(t) is not vp._ORDER_CACHE.get(id(t), (None, None, None))[2] for t in clones)        # other objects: computed afresh
+    assert masks(clones) == want
+    imps[2].mul_(-1.0)                                                                                             # modified in place: the entry is stale
+    assert vp._order_of(imps[2]) is not vp._ORDER_CACHE[id(imps[2])][2]
+    assert masks(imps) == masks([t.clone() for t in imps]) and masks(imps) != want
+    vp.precompute_orders(imps[:3])                                                                                # fewer than four blocks: nothing cached
+    assert not vp._ORDER_CACHE
+
+
 def test_mask_parity_report_theorem_and_fields():
     """ssp2vit.mask_parity: a block is `guaranteed` iff no neuron lies in the +-eps band of the cut, and then NO score
     perturbation of relative size < eps / 2 can change the mask (checked by perturbing adversarially and at random);
