@@ -54,10 +54,14 @@
 #define ATTN_SKIP_DEAD 0
 #endif
 typedef __attribute__((ext_vector_type(2))) float attn_f32x2;
-template <int NT>
+// LIVE (round 5): the number of live register groups of the last key tile as a COMPILE-TIME constant (1..3; 0 = not known: all four
+// groups computed, or ATTN_SKIP_DEAD's run-time count in the tools).  The engine knows `tokens` when it launches, so the persistent
+// kernels of the two hot geometries (197 tokens: 5 valid keys in the last tile; 257: 1) are instantiated with LIVE = 1: the dead
+// groups' maxima, exponentials and sums and the dead half's P V step are not emitted at all — no branch, one basic block as before.
+template <int NT, int LIVE = 0>
 __device__ __forceinline__ float softmax_tile(f32x16 (&sacc)[NT], const int tokens, const int lh, const float scale, int& live_groups) {
   const int rem = tokens - 32 * (NT - 1);                  // valid keys of the last tile, 1..32 (wave-uniform)
-  live_groups = ATTN_SKIP_DEAD ? __builtin_amdgcn_readfirstlane((rem + 7) >> 3) : 4;          // group g = registers 4g..4g+3 = keys 8g + 4 lh + 0..3 of the tile
+  live_groups = LIVE > 0 ? LIVE : (ATTN_SKIP_DEAD ? __builtin_amdgcn_readfirstlane((rem + 7) >> 3) : 4);          // group g = registers 4g..4g+3 = keys 8g + 4 lh + 0..3 of the tile
   float mx = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < NT - 1; ++kt)
@@ -400,7 +404,7 @@ __device__ unsigned long long* attn_stamp_ptr;    // [8 waves][256 slots] of wor
 #define ASTAMP(slot) do {} while (0)
 #endif
 
-template <int NT>
+template <int NT, int LIVE = 0>
 __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                                int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
                                                                int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0,
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
       }
     }
     int live_groups;
-    float sum = softmax_tile<NT>(sacc, tokens, lh, scale, live_groups);
+    float sum = softmax_tile<NT, LIVE>(sacc, tokens, lh, scale, live_groups);
 #ifdef ATTN_STAMPS
     asm volatile("" : "+v"(sum));
     ASTAMP(n * 4 + 2);                                       // softmax sum known
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
     for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        if (kt == NT - 1 && s2 == 1 && live_groups <= 2) continue;       // keys 16..31 of the last tile are all padding: P = 0 (wave-uniform)
+        if (kt == NT - 1 && s2 == 1 && (LIVE > 0 ? LIVE : live_groups) <= 2) continue;       // keys 16..31 of the last tile are all padding: P = 0 (wave-uniform)
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s2 + j];
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void attn64_persist_kernel(const bf16* __re
 // every byte of K and V before its first MFMA.  Waves 0..7 take query tiles 0..7, wave 0 also the ninth (one valid query).
 // The per-tile arithmetic is the instruction order of attn_fwd_kernel<80, NT, false> (DMA80 layout: 160-byte rows, unswizzled):
 // bit-identical outputs (tests flip SSP2_OPT_ATTN_PERSIST).
-template <int NT>
+template <int NT, int LIVE = 0>
 __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ out, int ldo,
                                                             int tokens, int dim, int heads, int n_items, float scale, RowMap rm,
                                                             int reverse = 0, int stagger = 0, uint8_t* __restrict__ out8 = nullptr, int ldo8 = 0,
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
           sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kt], 0, 0, 0);
         }
       }
-      const float sum = softmax_tile<NT>(sacc, tokens, lh, scale, live_groups);
+      const float sum = softmax_tile<NT, LIVE>(sacc, tokens, lh, scale, live_groups);
       inv = 1.0f / sum;
     };
     auto pv_store = [&](int qt) {
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(512) void attn80_persist_kernel(const bf16* __restr
       for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          if (kt == NT - 1 && s2 == 1 && live_groups <= 2) continue;     // keys 16..31 of the last tile are all padding: P = 0 (wave-uniform)
+          if (kt == NT - 1 && s2 == 1 && (LIVE > 0 ? LIVE : live_groups) <= 2) continue;     // keys 16..31 of the last tile are all padding: P = 0 (wave-uniform)
           bf16x8 pf;
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[j] = (bf16)sacc[kt][8 * s2 + j];

@@ -387,6 +387,17 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullp
       const long items = (long)e->d.heads * n;
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
+      // 197 tokens (every /16 model at 224 pixels): five valid keys in the seventh key tile = ONE live register group — the instantiation that
+      // knows it at compile time emits no maxima / exponentials / sums for the other three groups and no P V step for the dead half (attn.hip.h LIVE)
+      if (NT == 7 && (e->tokens - 32 * (NT - 1) + 7) >> 3 == 1 && e->opt[SSP2_OPT_ATTN_LIVE]) {
+        static bool lattr_done[kMaxDevices] = {};
+        if (!lattr_done[e->dev]) {
+          HIPCHK(hipFuncSetAttribute((const void*)attn64_persist_kernel<NT, (NT == 7 ? 1 : 0)>, hipFuncAttributeMaxDynamicSharedMemorySize, psmem));
+          lattr_done[e->dev] = true;
+        }
+        hipLaunchKernelGGL((attn64_persist_kernel<NT, (NT == 7 ? 1 : 0)>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
+                           e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim, e->fp8_sat, out8_scale);
+      } else
       hipLaunchKernelGGL((attn64_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
                          e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim, e->fp8_sat, out8_scale);
       HIPCHK(hipGetLastError());
@@ -406,6 +417,16 @@ static int launch_attn_t(ssp2_engine* e, int n, RowMap rm, uint8_t* out8 = nullp
       const long items = (long)e->d.heads * n;
       if (items > 0x7fffffffL) return fail(SSP2_EINVAL, "too many attention items");
       const int rev = next_dir(e);
+      // 257 tokens: ONE valid key in the ninth key tile = one live register group, known at compile time (attn.hip.h LIVE)
+      if (e->opt[SSP2_OPT_ATTN_LIVE]) {
+        static bool lattr_done[kMaxDevices] = {};
+        if (!lattr_done[e->dev]) {
+          HIPCHK(hipFuncSetAttribute((const void*)attn80_persist_kernel<NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, psmem));
+          lattr_done[e->dev] = true;
+        }
+        hipLaunchKernelGGL((attn80_persist_kernel<NT, 1>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
+                           e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim, e->fp8_sat, out8_scale);
+      } else
       hipLaunchKernelGGL((attn80_persist_kernel<NT>), dim3((unsigned)std::min<long>(items, e->n_cu)), dim3(512), psmem, e->stream, e->qkvbuf, ld,
                          e->obuf, D, e->tokens, D, e->d.heads, (int)items, 1.0f / sqrtf((float)DH), rm, rev, e->opt[SSP2_OPT_ATTN_STAGGER], out8, e->ld8_dim, e->fp8_sat, out8_scale);
       HIPCHK(hipGetLastError());
@@ -502,6 +523,7 @@ int ssp2_create(const ssp2_vit_desc* desc, ssp2_handle* out) {
     e->opt[SSP2_OPT_FP8_PROJ] = env_int("SSP2_FP8_PROJ", 1);
     e->opt[SSP2_OPT_BIG_TILE_MIN_ROWS] = std::max(256, env_int("SSP2_BIG_TILE_MIN_ROWS", kBigTileMinRowsDefault));
     e->opt[SSP2_OPT_NT_STORES] = env_int("SSP2_NT_STORES", 1);
+    e->opt[SSP2_OPT_ATTN_LIVE] = env_int("SSP2_ATTN_LIVE", 1);
 #ifdef SSP2_LAB
     e->opt[SSP2_OPT_DEFER_RESID] = env_int("SSP2_DEFER_RESID", 0);
 #else

@@ -30,7 +30,7 @@ T_KINDS = ["patch_w", "patch_b", "cls", "pos", "ln1_g", "ln1_b", "qkv_w", "qkv_b
            "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "lnf_g", "lnf_b", "head_w", "head_b"]
 SCORE_SITE = {"none": 0, "pre_gelu": 1, "post_gelu": 2}
 SCORE_CHAIN = {"fp32": 0, "bf16_ref": 1}
-OPTIONS = {"zigzag": 0, "attn_persist": 1, "ln_fusion": 2, "big_tiles": 3, "fc1_big_tiles": 4, "group256": 5, "patch_lds": 6, "attn_stagger": 7, "fp8_proj": 8, "big_tile_min_rows": 9, "nt_stores": 10, "defer_resid": 11}   # SSP2_OPT_*
+OPTIONS = {"zigzag": 0, "attn_persist": 1, "ln_fusion": 2, "big_tiles": 3, "fc1_big_tiles": 4, "group256": 5, "patch_lds": 6, "attn_stagger": 7, "fp8_proj": 8, "big_tile_min_rows": 9, "nt_stores": 10, "defer_resid": 11, "attn_live": 12}   # SSP2_OPT_*
 K_CLASS = {"gemm_fc1": 0, "gemm_fc2": 1, "gemm_qkv": 2, "gemm_proj": 3, "gemm_patch": 4, "gemm_head": 5,
            "attn": 6, "ln": 7, "score_finish": 8, "act_l2": 9, "other": 10}
 

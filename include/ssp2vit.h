@@ -100,10 +100,13 @@ int ssp2_set_cu_limit(ssp2_handle h, int n_cu);
  *                                                   it so that test-sized launches meet the large kernel
  *   SSP2_OPT_NT_STORES      1  SSP2_NT_STORES       the 256 x 256 GEMM writes its bf16 / e4m3 activation outputs (QKV, fc1) with non-temporal stores
  *   SSP2_OPT_DEFER_RESID    0  SSP2_DEFER_RESID     residual projections on the 256 x 256 GEMM park bf16(acc + bias) and add it to x during the NEXT
- *                                                   tile's main loop (bf16 operands, dim a multiple of 256); same bits as the direct epilogue */
+ *                                                   tile's main loop (bf16 operands, dim a multiple of 256); same bits as the direct epilogue
+ *   SSP2_OPT_ATTN_LIVE      1  SSP2_ATTN_LIVE       persistent attention at 197 / 257 tokens on the instantiation that knows at compile time that the
+ *                                                   last key tile holds ONE live register group (5 / 1 valid keys): the padding's maxima,
+ *                                                   exponentials, sums and P V half are not emitted; 0 = the general instantiation */
 enum { SSP2_OPT_ZIGZAG = 0, SSP2_OPT_ATTN_PERSIST, SSP2_OPT_LN_FUSION, SSP2_OPT_BIG_TILES, SSP2_OPT_FC1_BIG_TILES, SSP2_OPT_GROUP256,
        SSP2_OPT_PATCH_LDS, SSP2_OPT_ATTN_STAGGER, SSP2_OPT_FP8_PROJ, SSP2_OPT_BIG_TILE_MIN_ROWS, SSP2_OPT_NT_STORES,
-       SSP2_OPT_DEFER_RESID, SSP2_OPT_COUNT };
+       SSP2_OPT_DEFER_RESID, SSP2_OPT_ATTN_LIVE, SSP2_OPT_COUNT };
 int ssp2_set_option(ssp2_handle h, int option, int value);
 int ssp2_get_option(ssp2_handle h, int option);                             /* >= 0, or SSP2_EINVAL */
 

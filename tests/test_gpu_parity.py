@@ -450,6 +450,47 @@ def test_persistent_attention_is_bit_identical_to_the_one_item_kernel(gpu, cfg, 
         eng.close()
 
 
+@pytest.mark.parametrize("cfg", ["vit_small_patch16_224_d2", "vit_huge_patch14_224_d2"])
+def test_attention_that_knows_the_padding_at_compile_time_changes_no_bit(gpu, cfg):
+    """SSP2_OPT_ATTN_LIVE (default on): at 197 / 257 tokens the last key tile holds 5 / 1 valid keys = ONE live register group of four, and the
+    persistent kernels are instantiated with that as a compile-time constant — the dead groups' maxima, exponentials and sums and the dead
+    half's P V step are not emitted (v_exp_f32 per tile 112 -> 100, 177 -> 165).  The padding contributed exp2(-inf) = 0 to every sum and 0 x V to
+    every output, so the residual stream after two blocks, the stage-1 scores and the logits must be the SAME BITS with the option on and off,
+    contiguous and slab layout, below and above the CU count — d_h = 80 included (both arms split the 257th query the same way)."""
+    from ssp2vit.engine import VitEngine
+    from ssp2vit.weights import synthetic_weights
+    w = synthetic_weights(cfg, classes=10, seed=12, std=0.05, eps=1e-6, bias_std=0.02)
+    eng = VitEngine(w, max_images=160)
+    g = torch.Generator().manual_seed(6)
+    try:
+        assert eng.get_option("attn_live") == 1 and eng.get_option("attn_persist") == 1
+        for n, group in ((3, 0), (97, 0), (160, 0), (160, 32), (150, 64)):
+            px = torch.randn(n, 3, 224, 224, generator=g).to(gpu)
+            outs = []
+            ntok = eng.tokens
+            if group:      # slab layout: only the rows of real images are defined
+                mpad = eng.rows(2 * group, group) - eng.rows(group, group)
+                valid = torch.cat([torch.arange(s0 * mpad, s0 * mpad + min(group, n - s0 * group) * ntok)
+                                   for s0 in range((n + group - 1) // group)]).to(gpu)
+            else:
+                valid = torch.arange(n * ntok, device=gpu)
+            for flag in (1, 0):
+                eng.set_option("attn_live", flag)
+                x = eng.embed(px, group=group)
+                sc = eng.layers(x, n, score_site="pre_gelu", score_group=group) if group else eng.layers(x, n)
+                logits = eng.forward_logits(px)
+                torch.cuda.synchronize()
+                outs.append((x[valid].clone(), None if sc is None else sc.clone(), logits.clone()))
+            assert torch.equal(outs[0][0], outs[1][0]), f"n={n} group={group}: residual stream"
+            assert torch.equal(outs[0][2], outs[1][2]), f"n={n} group={group}: logits"
+            if group:
+                assert torch.equal(outs[0][1], outs[1][1]), f"n={n} group={group}: stage-1 scores"
+            assert torch.isfinite(outs[0][2]).all()
+    finally:
+        eng.set_option("attn_live", 1)
+        eng.close()
+
+
 @pytest.mark.parametrize("cfg,layout", [("vit_huge_patch14_224_d2", "timm"), ("vit_large_patch16_224_d2", "hf"),
                                         ("vit_small_patch16_224_d2", "timm"),
                                         # beside BASELINE's models: ViT-L/14 (257 tokens at d_h = 64), ViT-B/32 (50 tokens, 3072-wide
