@@ -28,7 +28,7 @@ from .planner import ModelStats, TwoSSPPlan, plan_from_stats
 
 __all__ = [
     "prune_vit_mlp_width", "evaluate_top1", "prune_vit_attention_blocks", "plan_2ssp_allocation",
-    "count_total_params", "count_block_params", "compute_actual_sparsity", "save_report", "TwoSSPPlan",
+    "count_total_params", "count_block_params", "compute_actual_sparsity", "save_cifar_adapter", "load_cifar_adapter", "save_report", "TwoSSPPlan",
     "mask_parity_report", "MASK_PARITY_EPS",
 ]
 
@@ -584,6 +584,64 @@ def _jsonable(o):
         if isinstance(o, dict):
             return {str(k): _jsonable(v) for k, v in o.items()}
         return str(o)
+
+
+# ----------------------------------------------------------------------------- classifier head / adapter files (reference :774-875)
+_ADAPTER_KEYS = ("state_dict", "classifier_type", "num_labels", "hidden_size", "timestamp", "extra")
+
+
+@torch.no_grad()
+def save_cifar_adapter(model: nn.Module, out_dir: str, filename: str = "adapter.pt", extra: Optional[Dict[str, Any]] = None) -> str:
+    """Reference :775-798 — the classifier (a Linear head, or the Linear -> GELU -> Linear adapter) of `model` as one file:
+    {"state_dict", "classifier_type", "num_labels", "hidden_size", "timestamp", "extra"}.  Host-only; returns the path."""
+    os.makedirs(out_dir, exist_ok=True)
+    head = model.classifier
+    cfg = getattr(model, "config", None)
+    values = (head.state_dict(), type(head).__name__, getattr(cfg, "num_labels", None), getattr(cfg, "hidden_size", None),
+              time.strftime("%Y-%m-%d %H:%M:%S"), dict(extra) if extra else {})
+    path = os.path.join(out_dir, filename)
+    torch.save(dict(zip(_ADAPTER_KEYS, values)), path)
+    return path
+
+
+@torch.no_grad()
+def load_cifar_adapter(path: str, model: nn.Module) -> nn.Module:
+    """Reference :800-875 — rebuilds the saved head on `model` (in place, returned): a file whose state dict holds "weight" is a Linear
+    classifier, one with "0.weight" / "2.weight" the bottleneck adapter Sequential(Linear(hidden, r, bias=False), GELU, Linear(r, labels));
+    shapes missing from the metadata are read off the tensors; `model.config.num_labels` follows.  RuntimeError where the reference
+    raises one (no hidden size, no label count, an adapter whose layers cannot be told).  The file is read with a loader that executes
+    nothing from it (weights_only)."""
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    sd = blob.get("state_dict", {})
+    kind = blob.get("classifier_type", "Linear")
+    labels, hidden_saved = blob.get("num_labels"), blob.get("hidden_size")
+    seen_hidden = seen_rank = seen_out = None
+    if "weight" in sd:
+        seen_out, seen_hidden = (int(v) for v in sd["weight"].shape)
+    elif "0.weight" in sd and "2.weight" in sd:
+        seen_rank, seen_hidden = (int(v) for v in sd["0.weight"].shape)
+        seen_out = int(sd["2.weight"].shape[0])
+    hidden = hidden_saved or getattr(getattr(model, "config", None), "hidden_size", None) or seen_hidden
+    if hidden is None:
+        raise RuntimeError("Cannot determine hidden size for adapter loading.")
+    if labels is None:
+        labels = seen_out
+    if kind == "Linear" or ("weight" in sd and "bias" in sd):
+        if labels is None:
+            raise RuntimeError("num_labels is None for Linear classifier.")
+        head: nn.Module = nn.Linear(int(hidden), int(labels))
+    else:
+        if seen_rank is None and "0.weight" in sd:
+            seen_rank = int(sd["0.weight"].shape[0])
+        if labels is None and "2.weight" in sd:
+            labels = int(sd["2.weight"].shape[0])
+        if seen_rank is None or labels is None:
+            raise RuntimeError("Cannot reconstruct adapter architecture from payload/state_dict.")
+        head = nn.Sequential(nn.Linear(int(hidden), seen_rank, bias=False), nn.GELU(), nn.Linear(seen_rank, int(labels), bias=True))
+    head.load_state_dict(sd)
+    model.classifier = head
+    model.config.num_labels = int(labels)
+    return model
 
 
 def save_report(report: Dict[str, Any], out_dir: str, run_id: Optional[str] = None) -> Dict[str, str]:

@@ -247,3 +247,56 @@ def test_the_reference_interface_is_really_compared_where_it_exists():
         assert m is not None and hasattr(m, "Auto2SSPInterface") and os.path.realpath(m.__file__).startswith(os.path.realpath(REF))
     else:
         assert ref_mc() is None
+
+
+@pytest.mark.parametrize("kind", ["linear", "adapter"])
+def test_classifier_head_files_round_trip_and_are_the_references(kind, tmp_path):
+    """save_cifar_adapter / load_cifar_adapter (reference src/vit_pruning.py:774-875, in its `__all__`): the head of an HF-layout model — a
+    Linear classifier or the bottleneck adapter Sequential(Linear(bias=False), GELU, Linear) — goes to one file and comes back onto another
+    model with the same logits; the file's keys are the reference's; metadata missing from the file is read off the tensors; the three
+    RuntimeErrors.  Where the real reference is importable its loader must read THIS build's file and this loader the reference's, with
+    equal tensors."""
+    from ssp2vit import vit_pruning as vp
+    import torch.nn as nn
+    src = tiny_model("hf", 2, 8, 24, 2, 10, seed=3)
+    if kind == "adapter":
+        torch.manual_seed(4)
+        src.classifier = nn.Sequential(nn.Linear(16, 5, bias=False), nn.GELU(), nn.Linear(5, 7, bias=True))
+        src.config.num_labels = 7
+    path = vp.save_cifar_adapter(src, str(tmp_path), "head.pt", extra={"note": 1})
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    assert sorted(blob) == sorted(["state_dict", "classifier_type", "num_labels", "hidden_size", "timestamp", "extra"])
+    assert blob["classifier_type"] == ("Linear" if kind == "linear" else "Sequential") and blob["extra"] == {"note": 1}
+    assert blob["num_labels"] == (10 if kind == "linear" else 7) and blob["hidden_size"] == 16
+    dst = tiny_model("hf", 2, 8, 24, 2, 3, seed=9)
+    assert vp.load_cifar_adapter(path, dst) is dst and dst.config.num_labels == blob["num_labels"]
+    feats = torch.randn(5, 16, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(dst.classifier(feats), src.classifier(feats))
+    # metadata missing: shapes come from the tensors
+    bare = {"state_dict": blob["state_dict"], "classifier_type": blob["classifier_type"]}
+    torch.save(bare, tmp_path / "bare.pt")
+    again = tiny_model("hf", 2, 8, 24, 2, 3, seed=10)
+    vp.load_cifar_adapter(str(tmp_path / "bare.pt"), again)
+    assert torch.equal(again.classifier(feats), src.classifier(feats)) and again.config.num_labels == blob["num_labels"]
+    # the reference's failures
+    torch.save({"state_dict": {}, "classifier_type": "Linear"}, tmp_path / "empty.pt")
+    nohid = tiny_model("hf", 2, 8, 24, 2, 3, seed=11); nohid.config.hidden_size = None
+    with pytest.raises(RuntimeError, match="hidden size"):
+        vp.load_cifar_adapter(str(tmp_path / "empty.pt"), nohid)
+    with pytest.raises(RuntimeError, match="num_labels is None"):
+        vp.load_cifar_adapter(str(tmp_path / "empty.pt"), tiny_model("hf", 2, 8, 24, 2, 3, seed=12))
+    torch.save({"state_dict": {}, "classifier_type": "Sequential"}, tmp_path / "empty_seq.pt")
+    with pytest.raises(RuntimeError, match="reconstruct adapter"):
+        vp.load_cifar_adapter(str(tmp_path / "empty_seq.pt"), tiny_model("hf", 2, 8, 24, 2, 3, seed=13))
+    R = ref_vp()
+    if R is not None:
+        theirs = tiny_model("hf", 2, 8, 24, 2, 3, seed=14)
+        R.load_cifar_adapter(path, theirs)                                  # the reference reads this build's file
+        assert torch.equal(theirs.classifier(feats), src.classifier(feats)) and theirs.config.num_labels == blob["num_labels"]
+        rpath = R.save_cifar_adapter(src, str(tmp_path), "ref_head.pt", extra={"note": 1})
+        rblob = torch.load(rpath, map_location="cpu", weights_only=True)
+        assert sorted(rblob) == sorted(blob) and all(torch.equal(rblob["state_dict"][k], blob["state_dict"][k]) for k in blob["state_dict"])
+        assert {k: rblob[k] for k in ("classifier_type", "num_labels", "hidden_size", "extra")} == {k: blob[k] for k in ("classifier_type", "num_labels", "hidden_size", "extra")}
+        ours = tiny_model("hf", 2, 8, 24, 2, 3, seed=15)
+        vp.load_cifar_adapter(rpath, ours)                                  # and this build reads the reference's
+        assert torch.equal(ours.classifier(feats), src.classifier(feats))
